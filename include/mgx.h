@@ -1,0 +1,159 @@
+/*
+ * mgx.h — C ABI of libmgx.so, the MI355X (gfx950) kernels behind the
+ * MusicGeneration hot path.
+ *
+ * The reference (Aalanli/MusicGeneration) is pure Python on PyTorch: it has no
+ * FFI of its own.  The drop-in boundary is therefore the Python module API
+ * (musicgeneration_amd/ mirrors model_baseline/alibi_unified.py etc.), and this
+ * header is the layer directly under it: one entry point per fused operator,
+ * each citing the reference lines whose ATen op sequence it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (a torch tensor's
+ *     data_ptr()); nothing is allocated, freed or retained by the library
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *     the call returns without synchronising
+ *   - `dtype` selects the storage type of activations: MGX_F32 or MGX_BF16;
+ *     statistics (lse, mean, rstd, losses) are always fp32
+ *   - return value: 0 on success, a negative MGX_E* code otherwise (never throws);
+ *     mgx_last_error_string() describes the last failure on the calling thread
+ *   - re-entrant and thread-safe: no mutable global state
+ *   - tensors are dense row-major with the shapes given per function
+ */
+#ifndef MGX_H
+#define MGX_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MGX_F32 = 0, MGX_BF16 = 1 };
+enum { MGX_ACT_GELU = 0, MGX_ACT_RELU = 1 };
+enum { MGX_OK = 0, MGX_EINVAL = -1, MGX_EUNSUPPORTED = -2, MGX_ELAUNCH = -3 };
+
+int mgx_version(void);
+const char* mgx_last_error_string(void);
+
+/* ---- ALiBi causal attention -------------------------------------------------
+ * Replaces SimpleAttention.multihead_attn + split_heads/combine_heads
+ * (model_baseline/alibi_unified.py:40-54,59-65; base_layers.py:69-79) and the
+ * materialised [H,S,S] mask of construct_alibi (alibi_unified.py:26-31).
+ *   qkv    [B,S,3,H,dh]  output of c_attn, read in place (q | k | v thirds of a row)
+ *   slopes [H] fp32      get_slopes(H) (alibi_unified.py:13-23)
+ *   out    [B,S,H,dh]    == combine_heads(softmax(q k^T/sqrt(dh) + slope_h*j + causal) v)
+ *   lse    [B,H,S] fp32  natural-log row normaliser of the shifted scores
+ *                        q.k/sqrt(dh) + slope_h*(j-i), kept for the backward
+ * The bias is evaluated as slope*(j-i): per row it differs from the reference's
+ * slope*j by a constant, which softmax cancels.
+ * bf16 with dh in {64,128} runs the MFMA flash kernel; every other case runs
+ * the generic wave-per-row kernel (fp32 math).
+ */
+int mgx_alibi_attn_fwd(const void* qkv, const float* slopes, void* out, float* lse,
+                       int B, int S, int H, int dh, int dtype, void* stream);
+
+/* Backward of the above.  dqkv [B,S,3,H,dh] receives dq | dk | dv (fully
+ * overwritten).  delta [B,H,S] fp32 is caller-provided scratch (rowsum(dout*out)). */
+int mgx_alibi_attn_bwd(const void* dout, const void* qkv, const void* out, const float* lse,
+                       const float* slopes, void* dqkv, float* delta,
+                       int B, int S, int H, int dh, int dtype, void* stream);
+
+/* ---- skew relative-position causal attention --------------------------------
+ * Replaces RelativeAttention.relative_attn + multihead_attn
+ * (old_models/relative_transformer.py:18-44): softmax((q k^T + rel)*dh^-1/2 + causal) v
+ * with rel[i,j] = q_i . E[h, max_seq-1-(i-j)]  (the pad/reshape skew, never materialised).
+ *   E [H,max_seq,dh] (same dtype as qkv); requires S <= max_seq.
+ */
+int mgx_rel_attn_fwd(const void* qkv, const void* E, void* out, float* lse,
+                     int B, int S, int H, int dh, int max_seq, int dtype, void* stream);
+
+/* dE [H,max_seq,dh] fp32, fully overwritten (rows < max_seq-S get zero). */
+int mgx_rel_attn_bwd(const void* dout, const void* qkv, const void* out, const float* lse,
+                     const void* E, void* dqkv, float* dE, float* delta,
+                     int B, int S, int H, int dh, int max_seq, int dtype, void* stream);
+
+/* ---- (dropout +) residual + LayerNorm -----------------------------------------
+ * Replaces `x = norm(drop(x1) + x)` (alibi_unified.py:88-89, 93-94) and, with
+ * res == NULL and p_drop == 0, the final Norm (base_layers.py:36-41).
+ *   a [T,d] branch output, res [T,d] or NULL, gamma/beta [d] fp32
+ *   z [T,d] (dtype) pre-norm sum kept for the backward (may be NULL for inference)
+ *   y [T,d], mean/rstd [T] fp32 (may be NULL when z is NULL)
+ * Dropout keeps an element when hash(seed, element index) >= p_drop and scales by 1/(1-p).
+ */
+int mgx_ln_residual_fwd(const void* a, const void* res, const float* gamma, const float* beta,
+                        void* y, void* z, float* mean, float* rstd,
+                        long T, int d, float eps, float p_drop, unsigned long long seed,
+                        int dtype, void* stream);
+
+/* dy2 may be NULL; otherwise the incoming gradient is dy + dy2 (fuses the
+ * residual-branch add of the backward).  dz [T,d] is the gradient wrt the
+ * pre-norm sum (= gradient of `res`); da [T,d] (may alias dz when p_drop==0, or
+ * be NULL) is dz with the dropout mask re-applied.  dgamma/dbeta [d] fp32 are
+ * overwritten; partial [nblk_max*2*d] fp32 scratch, nblk_max = mgx_ln_bwd_partial_rows(). */
+int mgx_ln_bwd_partial_rows(void);
+int mgx_ln_residual_bwd(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
+                        const float* gamma, void* dz, void* da, float* dgamma, float* dbeta, float* partial,
+                        long T, int d, float p_drop, unsigned long long seed, int dtype, void* stream);
+
+/* ---- bias + activation (+ dropout) ------------------------------------------------
+ * Replaces `drop(activation(linear1(x)))`'s elementwise tail (alibi_unified.py:90-91):
+ *   u [T,n] GEMM output WITHOUT bias; bias [n] fp32
+ *   pre [T,n] = u + bias (kept for the backward; may alias u), h [T,n] = drop(act(pre))
+ * act: MGX_ACT_GELU is the exact erf form (F.gelu default), MGX_ACT_RELU for the relative model.
+ */
+int mgx_bias_act_fwd(const void* u, const float* bias, void* pre, void* h,
+                     long T, int n, int act, float p_drop, unsigned long long seed, int dtype, void* stream);
+/* dpre [T,n] = dh * mask/(1-p) * act'(pre);  dbias [n] fp32 overwritten;
+ * partial scratch as for LayerNorm ([mgx_ln_bwd_partial_rows()*n] fp32). */
+int mgx_bias_act_bwd(const void* dh, const void* pre, void* dpre, float* dbias, float* partial,
+                     long T, int n, int act, float p_drop, unsigned long long seed, int dtype, void* stream);
+
+/* ---- softmax cross-entropy over the MIDI vocabulary --------------------------------
+ * Replaces F.cross_entropy(logits.transpose(-1,-2), y, weight, ignore_index)
+ * (alibi_unified.py:161; alibi_separated.py:193-195).
+ *   logits [T,ld] with the V class scores of this head at columns [col0, col0+V)
+ *   targets [T] int64; weight [V] fp32 or NULL; ignore_index < 0 disables it
+ *   row_loss [T] fp32 = w[y]*nll (0 for ignored rows); row_lse [T] fp32
+ *   sums fp32 [mgx_xent_sums_len()]: sums[0] = sum w[y]*nll, sums[1] = sum w[y] over
+ *   non-ignored rows (overwritten; the tail is scratch for the deterministic
+ *   two-stage reduction); the mean loss is sums[0]/sums[1]
+ */
+int mgx_xent_sums_len(void);
+int mgx_softmax_xent_fwd(const void* logits, const long long* targets, const float* weight,
+                         float* row_loss, float* row_lse, float* sums,
+                         long T, int V, int ld, int col0, long long ignore_index, int dtype, void* stream);
+/* dlogits [T,ld] columns [col0,col0+V) = gscale * w[y]/sums[1] * (softmax - onehot);
+ * gscale points at one fp32 on the device (upstream grad * loss weight). */
+int mgx_softmax_xent_bwd(const void* logits, const long long* targets, const float* weight,
+                         const float* row_lse, const float* sums, const float* gscale, void* dlogits,
+                         long T, int V, int ld, int col0, long long ignore_index, int dtype, void* stream);
+
+/* ---- KV-cached decode attention ------------------------------------------------------
+ * Replaces the full re-forward per generated token of inference_unified.py:12-21
+ * (O(L^2) attention per step) by attention of R new query rows against a cache.
+ *   q [B,R,H,dh]; kcache/vcache [B,H,Lmax,dh]; row r of q sits at absolute position
+ *   pos0 + r and attends keys 0..pos0+r (the cache must already hold them);
+ *   out [B,R,H,dh].  Wavefront-reduction softmax; HBM-bound.
+ */
+int mgx_decode_attn(const void* q, const void* kcache, const void* vcache, const float* slopes,
+                    void* out, int B, int R, int H, int dh, int Lmax, int pos0, int dtype, void* stream);
+/* Scatter R new k/v rows of qkv [B,R,3,H,dh] into the caches at positions pos0.. */
+int mgx_kv_append(const void* qkv, void* kcache, void* vcache,
+                  int B, int R, int H, int dh, int Lmax, int pos0, int dtype, void* stream);
+
+/* ---- fused AdamW ---------------------------------------------------------------------
+ * Replaces torch.optim.AdamW.step (build_everything_unified.py:42) for one flat
+ * chunk: decoupled weight decay, bias-corrected moments; also refreshes the bf16
+ * shadow copy of the weights when shadow != NULL.  grad may be fp32 or bf16.
+ */
+int mgx_adamw(float* param, const void* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+              long n, float lr, float beta1, float beta2, float eps, float weight_decay,
+              int step, float grad_scale, int grad_dtype, void* stream);
+
+/* Test hook (no reference counterpart): route attention through the generic
+ * kernels (on != 0) or restore the MFMA dispatch (on == 0). */
+void mgx_debug_force_generic_attention(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_H */

@@ -1,0 +1,133 @@
+"""Primitive layers with the reference's names, parameters and state_dict keys
+(base_layers.py), running on the libmgx kernels.
+
+Compute dtype: every module computes in fp32 unless bf16 is selected, either
+by the owning model's ``dtype='bf16'`` constructor kwarg or by an enclosing
+``torch.autocast`` context (the reference's ``mixed_precision=True`` path,
+train_utils.py:164; fp16 autocast is mapped to bf16 — no loss scaling needed).
+Parameters stay fp32 masters; bf16 shadows are cached per parameter version.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+def generate_square_subsequent_mask(sz, device):
+    """0 on/below the diagonal, -inf above (base_layers.py:19-22).  Kept for API
+    compatibility; the attention kernels never materialise it."""
+    return torch.triu(torch.full((sz, sz), float("-inf"), device=device), diagonal=1)
+
+
+def checkpoint_wrapper(module, *args, apply=False, over_ride=None):
+    """base_layers.py:6-16: activation checkpointing only when over_ride is True."""
+    if over_ride is True:
+        from torch.utils import checkpoint
+        return checkpoint.checkpoint(lambda *x: module(*x), *args)
+    return module(*args)
+
+
+def resolve_dtype(requested):
+    """fp32 / bf16 from a constructor kwarg value."""
+    if requested in (None, "fp32", "float32", torch.float32):
+        return torch.float32
+    if requested in ("bf16", "bfloat16", torch.bfloat16):
+        return torch.bfloat16
+    raise ValueError(f"dtype must be 'fp32' or 'bf16', got {requested!r}")
+
+
+def active_dtype(module_dtype):
+    """bf16 under autocast (any low-precision autocast dtype maps to bf16), else the module's own."""
+    if torch.is_autocast_enabled():
+        return torch.bfloat16
+    return module_dtype
+
+
+class ShadowCache:
+    """Compute-dtype copies of fp32 master parameters, refreshed when the master's version changes."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, p: torch.Tensor, dtype, shape=None):
+        if dtype == p.dtype:
+            t = p.detach()
+            return t if shape is None else t.view(shape)
+        key = (id(p), dtype)
+        ent = self._c.get(key)
+        if ent is None or ent[0] != p._version or ent[1].device != p.device:
+            ent = (p._version, p.detach().to(dtype))
+            self._c[key] = ent
+        return ent[1] if shape is None else ent[1].view(shape)
+
+    def clear(self):
+        self._c.clear()
+
+
+class Norm(nn.Module):
+    """Biased-variance layer norm with parameters g, b (base_layers.py:25-41) on the fused LN kernel."""
+
+    def __init__(self, n_state, axis=-1, epsilon=1e-5):
+        super().__init__()
+        if axis != -1:
+            raise ValueError("only axis=-1 is supported")
+        self.n_state = n_state
+        self.g = nn.Parameter(torch.ones([n_state]))
+        self.b = nn.Parameter(torch.zeros([n_state]))
+        self.axis = axis
+        self.epsilon = epsilon
+
+    def forward(self, x):
+        return ops.layer_norm(x, self.g, self.b, self.epsilon)
+
+
+class Conv1d(nn.Module):
+    """x @ w + b with w stored [1, nx, nf], N(0, stdev) init (base_layers.py:44-57)."""
+
+    def __init__(self, nf, nx, stdev=0.02):
+        super().__init__()
+        self.nf = nf
+        self.nx = nx
+        self.stdev = stdev
+        self.w = nn.Parameter(torch.normal(size=[1, nx, nf], mean=0.0, std=stdev))
+        self.b = nn.Parameter(torch.zeros([nf]))
+
+    def forward(self, x):
+        lead = x.shape[:-1]
+        w = self.w.view(self.nx, self.nf).to(x.dtype)
+        y = torch.addmm(self.b.to(x.dtype), x.reshape(-1, self.nx), w)
+        return y.view(*lead, self.nf)
+
+
+class Attention(nn.Module):
+    """Head split/merge helpers (base_layers.py:60-79).  The fused kernels read
+    the packed [B,S,3,H,dh] projection directly; these exist for API parity."""
+
+    def __init__(self, heads, n_state):
+        super().__init__()
+        assert n_state % heads == 0
+        self.heads = heads
+        self.n_state = n_state
+        self.depth = n_state // heads
+
+    def split_heads(self, x, batch, seq_len):
+        return x.reshape(batch, seq_len, self.heads, self.depth).permute(0, 2, 1, 3)
+
+    def combine_heads(self, x, batch, seq_len):
+        return x.permute(0, 2, 1, 3).reshape(batch, seq_len, self.n_state)
+
+
+class Mlp(nn.Module):
+    """conv_fc -> gelu -> conv_proj (base_layers.py:82-93)."""
+
+    def __init__(self, input_dim, proj_dim):
+        super().__init__()
+        self.input_dim = input_dim
+        self.proj_dim = proj_dim
+        self.conv_fc = Conv1d(proj_dim, input_dim)
+        self.conv_proj = Conv1d(input_dim, proj_dim)
+
+    def forward(self, x):
+        return self.conv_proj(nn.functional.gelu(self.conv_fc(x)))

@@ -1,0 +1,82 @@
+// C-ABI entry points that dispatch between kernel families, plus error state.
+#include "mgx_common.h"
+
+static thread_local char g_err[512] = "";
+
+void mgx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int mgx_version(void) { return 100; }
+extern "C" const char* mgx_last_error_string(void) { return g_err; }
+
+// attn_generic.hip
+int mgx_check_attn_shape(const char* fn, int B, int S, int H, int dh, int dtype);
+int mgx_attn_fwd_generic(int mode, const void* qkv, const float* slopes, const void* E, void* out, float* lse, int B,
+                         int S, int H, int dh, int max_seq, int dtype, hipStream_t st);
+int mgx_attn_bwd_generic(int mode, const void* dout, const void* qkv, const void* out, const float* lse,
+                         const float* slopes, const void* E, void* dqkv, float* dE, float* delta, int B, int S, int H,
+                         int dh, int max_seq, int dtype, hipStream_t st);
+// attn_mfma.hip
+bool mgx_attn_mfma_supported(int mode, int dh, int dtype);
+int mgx_attn_fwd_mfma(int mode, const void* qkv, const float* slopes, const void* E, void* out, float* lse, int B,
+                      int S, int H, int dh, int max_seq, hipStream_t st);
+int mgx_attn_bwd_mfma(int mode, const void* dout, const void* qkv, const void* out, const float* lse,
+                      const float* slopes, const void* E, void* dqkv, float* dE, float* delta, int B, int S, int H,
+                      int dh, int max_seq, hipStream_t st);
+
+static int g_force_generic = 0;
+// Test hook: route every attention call through the generic kernels (1) or restore dispatch (0).
+extern "C" void mgx_debug_force_generic_attention(int on) { g_force_generic = on; }
+
+extern "C" int mgx_alibi_attn_fwd(const void* qkv, const float* slopes, void* out, float* lse, int B, int S, int H,
+                                  int dh, int dtype, void* stream) {
+    MGX_REQUIRE(qkv && slopes && out && lse, MGX_EINVAL, "mgx_alibi_attn_fwd: null pointer");
+    int rc = mgx_check_attn_shape("mgx_alibi_attn_fwd", B, S, H, dh, dtype);
+    if (rc) return rc;
+    if (!g_force_generic && mgx_attn_mfma_supported(0, dh, dtype))
+        return mgx_attn_fwd_mfma(0, qkv, slopes, nullptr, out, lse, B, S, H, dh, 0, (hipStream_t)stream);
+    return mgx_attn_fwd_generic(0, qkv, slopes, nullptr, out, lse, B, S, H, dh, 0, dtype, (hipStream_t)stream);
+}
+
+extern "C" int mgx_alibi_attn_bwd(const void* dout, const void* qkv, const void* out, const float* lse,
+                                  const float* slopes, void* dqkv, float* delta, int B, int S, int H, int dh,
+                                  int dtype, void* stream) {
+    MGX_REQUIRE(dout && qkv && out && lse && slopes && dqkv && delta, MGX_EINVAL, "mgx_alibi_attn_bwd: null pointer");
+    int rc = mgx_check_attn_shape("mgx_alibi_attn_bwd", B, S, H, dh, dtype);
+    if (rc) return rc;
+    if (!g_force_generic && mgx_attn_mfma_supported(0, dh, dtype))
+        return mgx_attn_bwd_mfma(0, dout, qkv, out, lse, slopes, nullptr, dqkv, nullptr, delta, B, S, H, dh, 0,
+                                 (hipStream_t)stream);
+    return mgx_attn_bwd_generic(0, dout, qkv, out, lse, slopes, nullptr, dqkv, nullptr, delta, B, S, H, dh, 0, dtype,
+                                (hipStream_t)stream);
+}
+
+extern "C" int mgx_rel_attn_fwd(const void* qkv, const void* E, void* out, float* lse, int B, int S, int H, int dh,
+                                int max_seq, int dtype, void* stream) {
+    MGX_REQUIRE(qkv && E && out && lse, MGX_EINVAL, "mgx_rel_attn_fwd: null pointer");
+    int rc = mgx_check_attn_shape("mgx_rel_attn_fwd", B, S, H, dh, dtype);
+    if (rc) return rc;
+    MGX_REQUIRE(S <= max_seq, MGX_EINVAL, "mgx_rel_attn_fwd: S=%d exceeds max_seq=%d", S, max_seq);
+    if (!g_force_generic && mgx_attn_mfma_supported(1, dh, dtype))
+        return mgx_attn_fwd_mfma(1, qkv, nullptr, E, out, lse, B, S, H, dh, max_seq, (hipStream_t)stream);
+    return mgx_attn_fwd_generic(1, qkv, nullptr, E, out, lse, B, S, H, dh, max_seq, dtype, (hipStream_t)stream);
+}
+
+extern "C" int mgx_rel_attn_bwd(const void* dout, const void* qkv, const void* out, const float* lse, const void* E,
+                                void* dqkv, float* dE, float* delta, int B, int S, int H, int dh, int max_seq,
+                                int dtype, void* stream) {
+    MGX_REQUIRE(dout && qkv && out && lse && E && dqkv && dE && delta, MGX_EINVAL, "mgx_rel_attn_bwd: null pointer");
+    int rc = mgx_check_attn_shape("mgx_rel_attn_bwd", B, S, H, dh, dtype);
+    if (rc) return rc;
+    MGX_REQUIRE(S <= max_seq, MGX_EINVAL, "mgx_rel_attn_bwd: S=%d exceeds max_seq=%d", S, max_seq);
+    MGX_REQUIRE(max_seq <= 65535, MGX_EUNSUPPORTED, "mgx_rel_attn_bwd: max_seq too large");
+    if (!g_force_generic && mgx_attn_mfma_supported(1, dh, dtype))
+        return mgx_attn_bwd_mfma(1, dout, qkv, out, lse, nullptr, E, dqkv, dE, delta, B, S, H, dh, max_seq,
+                                 (hipStream_t)stream);
+    return mgx_attn_bwd_generic(1, dout, qkv, out, lse, nullptr, E, dqkv, dE, delta, B, S, H, dh, max_seq, dtype,
+                                (hipStream_t)stream);
+}

@@ -1,0 +1,283 @@
+// bf16 MFMA flash attention for gfx950 (head dim 64 or 128), causal + ALiBi.
+// Replaces SimpleAttention.multihead_attn (model_baseline/alibi_unified.py:40-54)
+// and the [H,S,S] mask buffer (alibi_unified.py:26-31): the bias slope_h*(j-i) is
+// folded into the initial MFMA accumulator, nothing S x S ever reaches HBM.
+//
+// Orientation ("query on the lane"): every product is arranged so that the
+// v_mfma_f32_32x32x16_bf16 result has the QUERY index on the lane (column) and
+// the reduced index of the NEXT product in its 16 registers (rows):
+//     S^T[j][i]  = K . Q^T        A = K rows (LDS, ds_read_b128), B = Q (registers)
+//     O^T[d][i] += V^T . P^T      A = V columns (LDS, ds_read_b64_tr_b16), B = P^T straight
+//                                 from the S^T accumulators (no LDS round trip)
+// so the softmax row statistics (one query per lane) need a single half-wave
+// exchange per tile, and the rescale factor is a per-lane scalar.
+//
+// Workgroup = 4 waves x 32 queries = 128 queries; K/V tiles of 64 keys are
+// staged global -> registers -> LDS with the loads of tile t+1 in flight under
+// the MFMAs of tile t.  LDS image: 8-row x 32-column sub-tiles (512 B) with an
+// XOR on the 16-byte chunk index, conflict-free for both the row reads and the
+// transposed reads (cdna_hip_programming.md T10 image (a)).
+#include "mgx_common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+template <int DH>
+struct Img {
+    static constexpr int CPR = DH / 8;        // 16-byte chunks per row
+    static constexpr int G8 = 8 * DH * 2;     // bytes per 8-row group
+    static constexpr int TILE_BYTES = 64 * DH * 2;
+    __device__ static __forceinline__ int off(int row, int ch) {
+        return G8 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+    }
+};
+
+__device__ __forceinline__ bf16x8 lds_read16(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+__device__ __forceinline__ bf16x8 lds_read_tr_pair(const char* p0, const char* p1) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+    union {
+        struct { s16x4 lo, hi; } s;
+        bf16x8 v;
+    } u;
+    u.s.lo = a;
+    u.s.hi = b;
+    return u.v;
+}
+
+__device__ __forceinline__ float half_swap_max(float v) {
+    // max over the two half-waves (lane l and l^32 hold the same query)
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_swap_sum(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& s, int base) {
+    bf16x8 r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = (bf16_t)s[base + k];
+    return r;
+}
+
+// Stage one [64 x DH] bf16 tile: global rows r0.. (row stride rs elements) -> registers.
+template <int DH>
+struct TileRegs {
+    bf16x8 v[DH / 32];
+};
+
+template <int DH>
+__device__ __forceinline__ void tile_load(TileRegs<DH>& t, const bf16_t* src, long rs, int r0, int S, int tid) {
+#pragma unroll
+    for (int n = 0; n < DH / 32; ++n) {
+        const int e = tid + 256 * n;
+        const int row = e / Img<DH>::CPR, ch = e % Img<DH>::CPR;
+        const int g = r0 + row;
+        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        t.v[n] = (g < S) ? *reinterpret_cast<const bf16x8*>(src + (long)g * rs + ch * 8) : z;
+    }
+}
+template <int DH>
+__device__ __forceinline__ void tile_store(const TileRegs<DH>& t, char* img, int tid) {
+#pragma unroll
+    for (int n = 0; n < DH / 32; ++n) {
+        const int e = tid + 256 * n;
+        const int row = e / Img<DH>::CPR, ch = e % Img<DH>::CPR;
+        *reinterpret_cast<bf16x8*>(img + Img<DH>::off(row, ch)) = t.v[n];
+    }
+}
+
+// Per-lane LDS byte offsets for the two access kinds (see header comment).
+template <int DH>
+struct LaneAddr {
+    int row0, row1;   // row read (A operand rows), k-step parity 0 / 1
+    int tr0, tr1;     // transposed read, first / second 4-row block of a k-step
+    __device__ __forceinline__ LaneAddr(int lane) {
+        const int l31 = lane & 31, h5 = lane >> 5;
+        row0 = Img<DH>::off(l31, h5);
+        row1 = Img<DH>::off(l31, 2 + h5);
+        const int q = (lane & 15) >> 2, p = lane & 3, g1 = (lane >> 4) & 1;
+        const int x = 2 * g1 + (p >> 1);
+        const int rb = 64 * (4 * h5 + q) + 8 * (p & 1);
+        tr0 = rb + 16 * (x ^ h5);
+        tr1 = rb + 16 * ((x ^ h5) ^ 2);
+    }
+    // A-operand rows [32*tb .. +32) of the tile, k-step ks (16 columns)
+    __device__ __forceinline__ int row_read(int tb, int ks) const {
+        return ((ks & 1) ? row1 : row0) + Img<DH>::G8 * 4 * tb + 512 * (ks >> 1);
+    }
+    // transposed A operand: columns [32*cb .. +32) on the lanes, reduced rows 32*tb + 16*s2 + {..}
+    __device__ __forceinline__ int tr_read(int tb, int s2, int u, int cb) const {
+        return (u ? tr1 : tr0) + Img<DH>::G8 * (4 * tb + 2 * s2 + u) + 512 * cb;
+    }
+};
+
+// ===========================================================================
+// forward
+// ===========================================================================
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv,
+                                                                const float* __restrict__ slopes,
+                                                                bf16_t* __restrict__ out, float* __restrict__ lse,
+                                                                int S, int H, float c /* scale*log2e */) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * Img<DH>::TILE_BYTES];
+    char* Ks = smem;
+    char* Vs = smem + Img<DH>::TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, h5 = lane >> 5;
+    const int qb = gridDim.x - 1 - blockIdx.x;          // heaviest (latest) query blocks first
+    const int q0 = qb * 128, qw0 = q0 + 32 * w;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const long rs = 3L * H * DH;
+    const bf16_t* base = qkv + (long)b * S * rs + (long)h * DH;
+    const bf16_t* kp = base + (long)H * DH;
+    const bf16_t* vp = base + 2L * H * DH;
+    const LaneAddr<DH> la(lane);
+
+    const int qi = qw0 + l31;
+    const bool qok = qi < S;
+    bf16x8 qf[DH / 16];
+#pragma unroll
+    for (int ks = 0; ks < DH / 16; ++ks) {
+        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        qf[ks] = qok ? *reinterpret_cast<const bf16x8*>(base + (long)qi * rs + ks * 16 + 8 * h5) : z;
+    }
+    const float sb = slopes[h] * LOG2E / c;              // bias per key step, in raw-score units
+
+    float m = -INFINITY, l = 0.f;
+    f32x16 o[DH / 32];
+#pragma unroll
+    for (int d = 0; d < DH / 32; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+
+    const int kmax = min(q0 + 128, S);                   // keys [0, kmax)
+    const int ntiles = (kmax + 63) / 64;
+    TileRegs<DH> kr, vr;
+    tile_load<DH>(kr, kp, rs, 0, S, tid);
+    tile_load<DH>(vr, vp, rs, 0, S, tid);
+    for (int t = 0; t < ntiles; ++t) {
+        const int j0 = t * 64;
+        __syncthreads();
+        tile_store<DH>(kr, Ks, tid);
+        tile_store<DH>(vr, Vs, tid);
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            tile_load<DH>(kr, kp, rs, j0 + 64, S, tid);
+            tile_load<DH>(vr, vp, rs, j0 + 64, S, tid);
+        }
+        if (j0 <= qw0 + 31) {                             // wave-uniform
+            f32x16 s[2];
+            const float lb = sb * (float)(j0 + 4 * h5 - qi);
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[tb][r] = lb + sb * (float)(32 * tb + (r & 3) + 8 * (r >> 2));
+#pragma unroll
+            for (int ks = 0; ks < DH / 16; ++ks)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+                    s[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(Ks + la.row_read(tb, ks)), qf[ks],
+                                                                   s[tb], 0, 0, 0);
+            if (j0 + 63 > qw0) {                          // diagonal tile: causal mask
+                const int dj = qi - j0 - 4 * h5;          // key offset (r-part) must be <= dj
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (32 * tb + (r & 3) + 8 * (r >> 2) > dj) s[tb][r] = -INFINITY;
+            }
+            float mx = s[0][0];
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tb][r]);
+            mx = half_swap_max(mx);
+            const float mn = fmaxf(m, mx);
+            const float alpha = exp2f((m - mn) * c);
+            const float mc = mn * c;
+            m = mn;
+            float psum = 0.f;
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = exp2f(fmaf(s[tb][r], c, -mc));
+                    s[tb][r] = p;
+                    psum += p;
+                }
+            l = fmaf(l, alpha, psum);
+#pragma unroll
+            for (int d = 0; d < DH / 32; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 pf = pack8(s[tb], 8 * s2);
+#pragma unroll
+                    for (int d = 0; d < DH / 32; ++d) {
+                        const bf16x8 vf = lds_read_tr_pair(Vs + la.tr_read(tb, s2, 0, d), Vs + la.tr_read(tb, s2, 1, d));
+                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    const float lt = half_swap_sum(l);
+    const float inv = 1.f / lt;
+    if (qok) {
+        bf16_t* op = out + ((long)b * S + qi) * H * DH + (long)h * DH;
+#pragma unroll
+        for (int d = 0; d < DH / 32; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = (bf16_t)(o[d][4 * g + k] * inv);
+                *reinterpret_cast<bf16x4*>(op + 32 * d + 8 * g + 4 * h5) = v;
+            }
+        if (h5 == 0) lse[((long)b * H + h) * S + qi] = (m * c + log2f(lt)) * LN2;
+    }
+}
+
+}  // namespace
+
+bool mgx_attn_mfma_supported(int mode, int dh, int dtype) {
+    return mode == 0 && dtype == MGX_BF16 && (dh == 64 || dh == 128);
+}
+
+int mgx_attn_fwd_mfma(int mode, const void* qkv, const float* slopes, const void* E, void* out, float* lse, int B,
+                      int S, int H, int dh, int max_seq, hipStream_t st) {
+    (void)E;
+    (void)max_seq;
+    MGX_REQUIRE(mode == 0, MGX_EUNSUPPORTED, "mgx_attn_fwd_mfma: mode %d", mode);
+    const float c = LOG2E / sqrtf((float)dh);
+    dim3 grid((S + 127) / 128, H, B);
+    if (dh == 64)
+        hipLaunchKernelGGL((attn_fwd_mfma_kernel<64>), grid, dim3(256), 0, st, (const bf16_t*)qkv, slopes,
+                           (bf16_t*)out, lse, S, H, c);
+    else
+        hipLaunchKernelGGL((attn_fwd_mfma_kernel<128>), grid, dim3(256), 0, st, (const bf16_t*)qkv, slopes,
+                           (bf16_t*)out, lse, S, H, c);
+    MGX_CHECK_LAUNCH("attn_fwd_mfma");
+    return MGX_OK;
+}
+
+int mgx_attn_bwd_generic(int mode, const void* dout, const void* qkv, const void* out, const float* lse,
+                         const float* slopes, const void* E, void* dqkv, float* dE, float* delta, int B, int S, int H,
+                         int dh, int max_seq, int dtype, hipStream_t st);
+
+int mgx_attn_bwd_mfma(int mode, const void* dout, const void* qkv, const void* out, const float* lse,
+                      const float* slopes, const void* E, void* dqkv, float* dE, float* delta, int B, int S, int H,
+                      int dh, int max_seq, hipStream_t st) {
+    // TODO(round 1, next step): MFMA backward; until then the generic kernels serve bf16 too.
+    return mgx_attn_bwd_generic(mode, dout, qkv, out, lse, slopes, E, dqkv, dE, delta, B, S, H, dh, max_seq, MGX_BF16,
+                                st);
+}

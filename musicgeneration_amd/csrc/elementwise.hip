@@ -1,0 +1,455 @@
+// HBM-bound fused row kernels: (dropout +) residual + LayerNorm forward/backward,
+// bias + GELU/ReLU (+ dropout) forward/backward, fused AdamW.
+// Replaces alibi_unified.py:88-94 (drop/add/norm, activation/drop) and
+// base_layers.py:36-41 (final Norm); AdamW = build_everything_unified.py:42.
+//
+// Layout: activations [T, d] row-major in fp32 or bf16; one wave per row, 16-byte
+// vector accesses (8 bf16 or 4 fp32 per lane per step), row held in registers
+// between the statistics pass and the normalise pass so each element is read once.
+#include "mgx_common.h"
+
+namespace {
+
+constexpr int PARTIAL_ROWS = 512;       // row-blocks of the two-stage column reductions
+
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    typedef f32x4 type;
+};
+template <> struct Vec<bf16_t> {
+    static constexpr int N = 8;
+    typedef bf16x8 type;
+};
+
+template <typename T, int N>
+__device__ __forceinline__ void load_vec(const T* p, float (&o)[N]) {
+    typename Vec<T>::type v = *reinterpret_cast<const typename Vec<T>::type*>(p);
+#pragma unroll
+    for (int k = 0; k < N; ++k) o[k] = to_f32(v[k]);
+}
+template <typename T, int N>
+__device__ __forceinline__ void store_vec(T* p, const float (&o)[N]) {
+    typename Vec<T>::type v;
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = from_f32<T>(o[k]);
+    *reinterpret_cast<typename Vec<T>::type*>(p) = v;
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm forward.  One wave per row; NV vectors of Vec<T>::N per lane.
+// ---------------------------------------------------------------------------
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ a, const T* __restrict__ res,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      T* __restrict__ y, T* __restrict__ z, float* __restrict__ mean,
+                                                      float* __restrict__ rstd, long T_rows, int d, float eps,
+                                                      float p_drop, unsigned long long seed) {
+    constexpr int N = Vec<T>::N;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= T_rows) return;
+    const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    float v[NV][N];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int col = (c * 64 + lane) * N;
+        if (col < d) {
+            load_vec<T, N>(a + row * d + col, v[c]);
+            if (p_drop > 0.f) {
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+                    v[c][k] = mgx_uniform(seed, (unsigned long long)(row * d + col + k)) >= p_drop ? v[c][k] * keep_scale : 0.f;
+            }
+            if (res) {
+                float r[N];
+                load_vec<T, N>(res + row * d + col, r);
+#pragma unroll
+                for (int k = 0; k < N; ++k) v[c][k] += r[k];
+            }
+            if (z) {
+                store_vec<T, N>(z + row * d + col, v[c]);
+                // statistics are taken on the value the backward will re-read
+#pragma unroll
+                for (int k = 0; k < N; ++k) v[c][k] = to_f32(from_f32<T>(v[c][k]));
+            }
+#pragma unroll
+            for (int k = 0; k < N; ++k) sum += v[c][k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[c][k] = 0.f;
+        }
+    }
+    const float mu = wave_sum(sum) / (float)d;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int col = (c * 64 + lane) * N;
+        if (col < d) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const float t = v[c][k] - mu;
+                sq = fmaf(t, t, sq);
+            }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(sq) / (float)d + eps);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int col = (c * 64 + lane) * N;
+        if (col < d) {
+            float o[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) o[k] = (v[c][k] - mu) * rs * gamma[col + k] + beta[col + k];
+            store_vec<T, N>(y + row * d + col, o);
+        }
+    }
+    if (lane == 0 && mean) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm backward.  One wave per row for dz; per-block partial sums of
+// dgamma/dbeta in LDS -> partial[blk][2][d]; a second kernel reduces the blocks.
+// ---------------------------------------------------------------------------
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
+                                                      const T* __restrict__ z, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                      T* __restrict__ dz, T* __restrict__ da,
+                                                      float* __restrict__ partial, long T_rows, int d, float p_drop,
+                                                      unsigned long long seed) {
+    constexpr int N = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][2][d]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    float g_acc[NV][N], b_acc[NV][N];
+#pragma unroll
+    for (int c = 0; c < NV; ++c)
+#pragma unroll
+        for (int k = 0; k < N; ++k) g_acc[c][k] = b_acc[c][k] = 0.f;
+
+    for (long row = (long)blockIdx.x * 4 + w; row < T_rows; row += (long)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float g[NV][N], xh[NV][N];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const int col = (c * 64 + lane) * N;
+            if (col < d) {
+                float zz[N];
+                load_vec<T, N>(dy + row * d + col, g[c]);
+                if (dy2) {
+                    float t[N];
+                    load_vec<T, N>(dy2 + row * d + col, t);
+#pragma unroll
+                    for (int k = 0; k < N; ++k) g[c][k] += t[k];
+                }
+                load_vec<T, N>(z + row * d + col, zz);
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    xh[c][k] = (zz[k] - mu) * rs;
+                    b_acc[c][k] += g[c][k];
+                    g_acc[c][k] = fmaf(g[c][k], xh[c][k], g_acc[c][k]);
+                    g[c][k] *= gamma[col + k];          // dxhat
+                    s1 += g[c][k];
+                    s2 = fmaf(g[c][k], xh[c][k], s2);
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)d;
+        s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const int col = (c * 64 + lane) * N;
+            if (col < d) {
+                float o[N];
+#pragma unroll
+                for (int k = 0; k < N; ++k) o[k] = (g[c][k] - s1 - xh[c][k] * s2) * rs;
+                store_vec<T, N>(dz + row * d + col, o);
+                if (da && (da != dz || p_drop > 0.f)) {
+                    if (p_drop > 0.f) {
+#pragma unroll
+                        for (int k = 0; k < N; ++k)
+                            o[k] = mgx_uniform(seed, (unsigned long long)(row * d + col + k)) >= p_drop ? o[k] * keep_scale : 0.f;
+                    }
+                    store_vec<T, N>(da + row * d + col, o);
+                }
+            }
+        }
+    }
+    // block reduction of the 4 waves' column partials
+    float* sg = smem + (size_t)w * 2 * d;
+    float* sb = sg + d;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int col = (c * 64 + lane) * N;
+        if (col < d) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                sg[col + k] = g_acc[c][k];
+                sb[col + k] = b_acc[c][k];
+            }
+        }
+    }
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * 2 * d;
+    for (int e = threadIdx.x; e < 2 * d; e += 256)
+        out[e] = smem[e] + smem[2 * d + e] + smem[4 * d + e] + smem[6 * d + e];
+}
+
+// out0[c] = sum_r partial[r][0][c]; out1[c] = sum_r partial[r][1][c]   (nseg = 1 or 2)
+__global__ void column_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out0,
+                                     float* __restrict__ out1, int nblk, int d, int nseg) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nseg * d) return;
+    float s = 0.f;
+    for (int r = 0; r < nblk; ++r) s += partial[(size_t)r * nseg * d + c];
+    if (c < d) out0[c] = s;
+    else out1[c - d] = s;
+}
+
+// ---------------------------------------------------------------------------
+// bias + activation (+ dropout)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float act_fwd(float x, int act) {
+    if (act == MGX_ACT_RELU) return fmaxf(x, 0.f);
+    return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float act_grad(float x, int act) {
+    if (act == MGX_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bias_act_fwd_kernel(const T* __restrict__ u, const float* __restrict__ bias,
+                                                            T* __restrict__ pre, T* __restrict__ h, long total, int n,
+                                                            int act, float p_drop, unsigned long long seed) {
+    constexpr int N = Vec<T>::N;
+    const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * N; e < total; e += (long)gridDim.x * 256 * N) {
+        const int col = (int)(e % n);
+        float v[N], o[N];
+        load_vec<T, N>(u + e, v);
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] += bias[col + k];
+        if (pre) {
+            store_vec<T, N>(pre + e, v);
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[k] = to_f32(from_f32<T>(v[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            o[k] = act_fwd(v[k], act);
+            if (p_drop > 0.f) o[k] = mgx_uniform(seed, (unsigned long long)(e + k)) >= p_drop ? o[k] * keep_scale : 0.f;
+        }
+        store_vec<T, N>(h + e, o);
+    }
+}
+
+// dpre = dh * mask * act'(pre); partial[blk][n] column sums for dbias.
+// Block handles rows blk, blk+grid, ...; thread t handles column vectors t, t+256, ...
+template <typename T>
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ pre,
+                                                            T* __restrict__ dpre, float* __restrict__ partial,
+                                                            long T_rows, int n, int act, float p_drop,
+                                                            unsigned long long seed) {
+    constexpr int N = Vec<T>::N;
+    const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (int col = threadIdx.x * N; col < n; col += 256 * N) {
+        float acc[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] = 0.f;
+        for (long row = blockIdx.x; row < T_rows; row += gridDim.x) {
+            const long e = row * n + col;
+            float g[N], x[N];
+            load_vec<T, N>(dh + e, g);
+            load_vec<T, N>(pre + e, x);
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                if (p_drop > 0.f) g[k] = mgx_uniform(seed, (unsigned long long)(e + k)) >= p_drop ? g[k] * keep_scale : 0.f;
+                g[k] *= act_grad(x[k], act);
+            }
+            store_vec<T, N>(dpre + e, g);
+#pragma unroll
+            for (int k = 0; k < N; ++k) acc[k] += to_f32(from_f32<T>(g[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) partial[(size_t)blockIdx.x * n + col + k] = acc[k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// AdamW (decoupled weight decay, torch.optim.AdamW semantics)
+// ---------------------------------------------------------------------------
+template <typename G>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const G* __restrict__ g,
+                                                     float* __restrict__ m, float* __restrict__ v,
+                                                     bf16_t* __restrict__ shadow, long n, float lr, float b1, float b2,
+                                                     float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gr = to_f32(g[i]) * gscale;
+        float w = p[i];
+        w -= lr * wd * w;
+        const float mm = b1 * m[i] + (1.f - b1) * gr;
+        const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mm;
+        v[i] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        w -= (lr / bc1) * (mm / denom);
+        p[i] = w;
+        if (shadow) shadow[i] = (bf16_t)w;
+    }
+}
+
+template <typename T>
+int ln_fwd_launch(const void* a, const void* res, const float* gamma, const float* beta, void* y, void* z,
+                  float* mean, float* rstd, long T_rows, int d, float eps, float p, unsigned long long seed,
+                  hipStream_t st) {
+    constexpr int N = Vec<T>::N;
+    const int nv = (d + 64 * N - 1) / (64 * N);
+    dim3 grid((unsigned)((T_rows + 3) / 4)), block(256);
+#define LN_FWD_CASE(NVV)                                                                                         \
+    hipLaunchKernelGGL((ln_fwd_kernel<T, NVV>), grid, block, 0, st, (const T*)a, (const T*)res, gamma, beta,  \
+                       (T*)y, (T*)z, mean, rstd, T_rows, d, eps, p, seed)
+    if (nv <= 1) LN_FWD_CASE(1);
+    else if (nv <= 2) LN_FWD_CASE(2);
+    else if (nv <= 4) LN_FWD_CASE(4);
+    else LN_FWD_CASE(8);
+#undef LN_FWD_CASE
+    MGX_CHECK_LAUNCH("ln_fwd");
+    return MGX_OK;
+}
+
+template <typename T>
+int ln_bwd_launch(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
+                  const float* gamma, void* dz, void* da, float* dgamma, float* dbeta, float* partial, long T_rows,
+                  int d, float p, unsigned long long seed, hipStream_t st) {
+    constexpr int N = Vec<T>::N;
+    const int nv = (d + 64 * N - 1) / (64 * N);
+    const int nblk = (int)((T_rows + 3) / 4 < PARTIAL_ROWS ? (T_rows + 3) / 4 : PARTIAL_ROWS);
+    const size_t smem = (size_t)8 * d * sizeof(float);
+    dim3 grid(nblk), block(256);
+#define LN_BWD_CASE(NVV)                                                                                          \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, NVV>), grid, block, smem, st, (const T*)dy, (const T*)dy2, (const T*)z, \
+                       mean, rstd, gamma, (T*)dz, (T*)da, partial, T_rows, d, p, seed)
+    if (nv <= 1) LN_BWD_CASE(1);
+    else if (nv <= 2) LN_BWD_CASE(2);
+    else if (nv <= 4) LN_BWD_CASE(4);
+    else LN_BWD_CASE(8);
+#undef LN_BWD_CASE
+    MGX_CHECK_LAUNCH("ln_bwd");
+    hipLaunchKernelGGL(column_reduce_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, st, partial, dgamma, dbeta, nblk,
+                       d, 2);
+    MGX_CHECK_LAUNCH("ln_bwd_reduce");
+    return MGX_OK;
+}
+
+}  // namespace
+
+extern "C" int mgx_ln_bwd_partial_rows(void) { return PARTIAL_ROWS; }
+
+extern "C" int mgx_ln_residual_fwd(const void* a, const void* res, const float* gamma, const float* beta, void* y,
+                                   void* z, float* mean, float* rstd, long T, int d, float eps, float p_drop,
+                                   unsigned long long seed, int dtype, void* stream) {
+    MGX_REQUIRE(a && gamma && beta && y, MGX_EINVAL, "mgx_ln_residual_fwd: null pointer");
+    MGX_REQUIRE(T > 0 && d > 0, MGX_EINVAL, "mgx_ln_residual_fwd: T=%ld d=%d", T, d);
+    MGX_REQUIRE(dtype == MGX_F32 || dtype == MGX_BF16, MGX_EINVAL, "mgx_ln_residual_fwd: bad dtype %d", dtype);
+    const int N = dtype == MGX_F32 ? 4 : 8;
+    MGX_REQUIRE(d % N == 0, MGX_EUNSUPPORTED, "mgx_ln_residual_fwd: d=%d must be a multiple of %d", d, N);
+    MGX_REQUIRE(d <= 64 * N * 8, MGX_EUNSUPPORTED, "mgx_ln_residual_fwd: d=%d too large (max %d)", d, 64 * N * 8);
+    MGX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, MGX_EINVAL, "mgx_ln_residual_fwd: p_drop=%f", p_drop);
+    MGX_REQUIRE((z == nullptr) || (mean && rstd), MGX_EINVAL, "mgx_ln_residual_fwd: z without mean/rstd");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MGX_F32)
+        return ln_fwd_launch<float>(a, res, gamma, beta, y, z, mean, rstd, T, d, eps, p_drop, seed, st);
+    return ln_fwd_launch<bf16_t>(a, res, gamma, beta, y, z, mean, rstd, T, d, eps, p_drop, seed, st);
+}
+
+extern "C" int mgx_ln_residual_bwd(const void* dy, const void* dy2, const void* z, const float* mean,
+                                   const float* rstd, const float* gamma, void* dz, void* da, float* dgamma,
+                                   float* dbeta, float* partial, long T, int d, float p_drop, unsigned long long seed,
+                                   int dtype, void* stream) {
+    MGX_REQUIRE(dy && z && mean && rstd && gamma && dz && dgamma && dbeta && partial, MGX_EINVAL,
+                "mgx_ln_residual_bwd: null pointer");
+    MGX_REQUIRE(T > 0 && d > 0, MGX_EINVAL, "mgx_ln_residual_bwd: T=%ld d=%d", T, d);
+    MGX_REQUIRE(dtype == MGX_F32 || dtype == MGX_BF16, MGX_EINVAL, "mgx_ln_residual_bwd: bad dtype %d", dtype);
+    const int N = dtype == MGX_F32 ? 4 : 8;
+    MGX_REQUIRE(d % N == 0 && d <= 64 * N * 8, MGX_EUNSUPPORTED, "mgx_ln_residual_bwd: unsupported d=%d", d);
+    MGX_REQUIRE((size_t)8 * d * sizeof(float) <= 64 * 1024, MGX_EUNSUPPORTED, "mgx_ln_residual_bwd: d=%d too large", d);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MGX_F32)
+        return ln_bwd_launch<float>(dy, dy2, z, mean, rstd, gamma, dz, da, dgamma, dbeta, partial, T, d, p_drop, seed, st);
+    return ln_bwd_launch<bf16_t>(dy, dy2, z, mean, rstd, gamma, dz, da, dgamma, dbeta, partial, T, d, p_drop, seed, st);
+}
+
+extern "C" int mgx_bias_act_fwd(const void* u, const float* bias, void* pre, void* h, long T, int n, int act,
+                                float p_drop, unsigned long long seed, int dtype, void* stream) {
+    MGX_REQUIRE(u && bias && h, MGX_EINVAL, "mgx_bias_act_fwd: null pointer");
+    MGX_REQUIRE(T > 0 && n > 0, MGX_EINVAL, "mgx_bias_act_fwd: T=%ld n=%d", T, n);
+    MGX_REQUIRE(dtype == MGX_F32 || dtype == MGX_BF16, MGX_EINVAL, "mgx_bias_act_fwd: bad dtype %d", dtype);
+    MGX_REQUIRE(act == MGX_ACT_GELU || act == MGX_ACT_RELU, MGX_EINVAL, "mgx_bias_act_fwd: bad act %d", act);
+    const int N = dtype == MGX_F32 ? 4 : 8;
+    MGX_REQUIRE(n % N == 0, MGX_EUNSUPPORTED, "mgx_bias_act_fwd: n=%d must be a multiple of %d", n, N);
+    const long total = T * n;
+    long blocks = (total / N + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MGX_F32)
+        hipLaunchKernelGGL((bias_act_fwd_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)u, bias,
+                           (float*)pre, (float*)h, total, n, act, p_drop, seed);
+    else
+        hipLaunchKernelGGL((bias_act_fwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)u,
+                           bias, (bf16_t*)pre, (bf16_t*)h, total, n, act, p_drop, seed);
+    MGX_CHECK_LAUNCH("bias_act_fwd");
+    return MGX_OK;
+}
+
+extern "C" int mgx_bias_act_bwd(const void* dh, const void* pre, void* dpre, float* dbias, float* partial, long T,
+                                int n, int act, float p_drop, unsigned long long seed, int dtype, void* stream) {
+    MGX_REQUIRE(dh && pre && dpre && dbias && partial, MGX_EINVAL, "mgx_bias_act_bwd: null pointer");
+    MGX_REQUIRE(T > 0 && n > 0, MGX_EINVAL, "mgx_bias_act_bwd: T=%ld n=%d", T, n);
+    MGX_REQUIRE(dtype == MGX_F32 || dtype == MGX_BF16, MGX_EINVAL, "mgx_bias_act_bwd: bad dtype %d", dtype);
+    const int N = dtype == MGX_F32 ? 4 : 8;
+    MGX_REQUIRE(n % N == 0, MGX_EUNSUPPORTED, "mgx_bias_act_bwd: n=%d must be a multiple of %d", n, N);
+    const int nblk = (int)(T < PARTIAL_ROWS ? T : PARTIAL_ROWS);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MGX_F32)
+        hipLaunchKernelGGL((bias_act_bwd_kernel<float>), dim3(nblk), dim3(256), 0, st, (const float*)dh,
+                           (const float*)pre, (float*)dpre, partial, T, n, act, p_drop, seed);
+    else
+        hipLaunchKernelGGL((bias_act_bwd_kernel<bf16_t>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)dh,
+                           (const bf16_t*)pre, (bf16_t*)dpre, partial, T, n, act, p_drop, seed);
+    MGX_CHECK_LAUNCH("bias_act_bwd");
+    hipLaunchKernelGGL(column_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, dbias, dbias, nblk, n, 1);
+    MGX_CHECK_LAUNCH("bias_act_bwd_reduce");
+    return MGX_OK;
+}
+
+extern "C" int mgx_adamw(float* param, const void* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, long n,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                         float grad_scale, int grad_dtype, void* stream) {
+    MGX_REQUIRE(param && grad && exp_avg && exp_avg_sq, MGX_EINVAL, "mgx_adamw: null pointer");
+    MGX_REQUIRE(n > 0 && step >= 1, MGX_EINVAL, "mgx_adamw: n=%ld step=%d", n, step);
+    MGX_REQUIRE(grad_dtype == MGX_F32 || grad_dtype == MGX_BF16, MGX_EINVAL, "mgx_adamw: bad grad dtype");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (grad_dtype == MGX_F32)
+        hipLaunchKernelGGL((adamw_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, param, (const float*)grad,
+                           exp_avg, exp_avg_sq, (bf16_t*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
+                           grad_scale);
+    else
+        hipLaunchKernelGGL((adamw_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, param, (const bf16_t*)grad,
+                           exp_avg, exp_avg_sq, (bf16_t*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
+                           grad_scale);
+    MGX_CHECK_LAUNCH("adamw");
+    return MGX_OK;
+}

@@ -1,0 +1,394 @@
+"""Thin torch wrappers over the C ABI (include/mgx.h): tensors in, tensors out.
+
+Each wrapper validates shapes/dtypes/contiguity on the host (a kernel fault can
+reset the whole GPU), passes raw device pointers plus the current HIP stream to
+libmgx.so and returns torch tensors.  The autograd.Function classes give the
+fused operators a backward; `fused_decoder_block` runs a whole post-LN block
+(alibi_unified.py:86-95) as one autograd node.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+_ACT = {"gelu": _lib.ACT_GELU, "relu": _lib.ACT_RELU}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"musicgeneration_amd kernels take float32 or bfloat16, got {t.dtype}") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: torch.Tensor, name: str, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: musicgeneration_amd runs on the GPU only (tensor is on {t.device}); "
+                           "there is no CPU fallback")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+def new_seed() -> int:
+    """Dropout seed drawn from torch's CPU generator (no device sync)."""
+    return int(torch.empty((), dtype=torch.int64).random_().item()) & ((1 << 62) - 1)
+
+
+# ---------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------
+def alibi_attn_fwd(qkv: torch.Tensor, slopes: torch.Tensor, n_heads: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """qkv [B,S,3*d] -> (out [B,S,d], lse [B,H,S])."""
+    _need(qkv, "qkv")
+    _need(slopes, "slopes", torch.float32)
+    B, S, d3 = qkv.shape
+    d = d3 // 3
+    if d3 != 3 * d or d % n_heads or slopes.numel() != n_heads:
+        raise ValueError(f"bad attention shapes qkv={tuple(qkv.shape)} heads={n_heads} slopes={slopes.numel()}")
+    out = torch.empty(B, S, d, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B, n_heads, S, dtype=torch.float32, device=qkv.device)
+    check(lib.mgx_alibi_attn_fwd(_p(qkv), _p(slopes), _p(out), _p(lse), B, S, n_heads, d // n_heads, _dt(qkv), _stream()),
+          "mgx_alibi_attn_fwd")
+    return out, lse
+
+
+def alibi_attn_bwd(dout, qkv, out, lse, slopes, n_heads: int) -> torch.Tensor:
+    _need(dout, "dout", qkv.dtype)
+    B, S, d3 = qkv.shape
+    d = d3 // 3
+    if dout.shape != out.shape or out.shape != (B, S, d):
+        raise ValueError("bad attention backward shapes")
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    check(lib.mgx_alibi_attn_bwd(_p(dout), _p(qkv), _p(out), _p(lse), _p(slopes), _p(dqkv), _p(delta), B, S, n_heads,
+                                 d // n_heads, _dt(qkv), _stream()), "mgx_alibi_attn_bwd")
+    return dqkv
+
+
+def rel_attn_fwd(qkv: torch.Tensor, E: torch.Tensor, n_heads: int):
+    _need(qkv, "qkv")
+    _need(E, "E", qkv.dtype)
+    B, S, d3 = qkv.shape
+    d = d3 // 3
+    H, M, dh = E.shape
+    if d3 != 3 * d or H != n_heads or dh * H != d or S > M:
+        raise ValueError(f"bad relative attention shapes qkv={tuple(qkv.shape)} E={tuple(E.shape)}")
+    out = torch.empty(B, S, d, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=qkv.device)
+    check(lib.mgx_rel_attn_fwd(_p(qkv), _p(E), _p(out), _p(lse), B, S, H, dh, M, _dt(qkv), _stream()), "mgx_rel_attn_fwd")
+    return out, lse
+
+
+def rel_attn_bwd(dout, qkv, out, lse, E, n_heads: int):
+    _need(dout, "dout", qkv.dtype)
+    B, S, d3 = qkv.shape
+    H, M, dh = E.shape
+    dqkv = torch.empty_like(qkv)
+    dE = torch.empty(H, M, dh, dtype=torch.float32, device=qkv.device)
+    delta = torch.empty_like(lse)
+    check(lib.mgx_rel_attn_bwd(_p(dout), _p(qkv), _p(out), _p(lse), _p(E), _p(dqkv), _p(dE), _p(delta), B, S, H, dh, M,
+                               _dt(qkv), _stream()), "mgx_rel_attn_bwd")
+    return dqkv, dE
+
+
+# ---------------------------------------------------------------------------
+# (dropout +) residual + LayerNorm
+# ---------------------------------------------------------------------------
+def ln_residual_fwd(a, res, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, save=True):
+    """y = LN(dropout(a) + res).  Returns (y, z, mean, rstd); z/mean/rstd are None when save=False."""
+    _need(a, "a")
+    _need(gamma, "gamma", torch.float32)
+    _need(beta, "beta", torch.float32)
+    d = a.shape[-1]
+    T = a.numel() // d
+    if res is not None:
+        _need(res, "res", a.dtype)
+        if res.shape != a.shape:
+            raise ValueError("residual shape mismatch")
+    if gamma.numel() != d or beta.numel() != d:
+        raise ValueError("gamma/beta size mismatch")
+    y = torch.empty_like(a)
+    z = torch.empty_like(a) if save else None
+    mean = torch.empty(T, dtype=torch.float32, device=a.device) if save else None
+    rstd = torch.empty(T, dtype=torch.float32, device=a.device) if save else None
+    check(lib.mgx_ln_residual_fwd(_p(a), _p(res), _p(gamma), _p(beta), _p(y), _p(z), _p(mean), _p(rstd), T, d, eps,
+                                  float(p_drop), seed, _dt(a), _stream()), "mgx_ln_residual_fwd")
+    return y, z, mean, rstd
+
+
+_PARTIAL_ROWS = lib.mgx_ln_bwd_partial_rows()
+
+
+def ln_residual_bwd(dy, dy2, z, mean, rstd, gamma, p_drop=0.0, seed=0):
+    """Returns (dz, da, dgamma, dbeta); da is dz when p_drop == 0."""
+    _need(dy, "dy", z.dtype)
+    if dy2 is not None:
+        _need(dy2, "dy2", z.dtype)
+    d = z.shape[-1]
+    T = z.numel() // d
+    if dy.numel() != z.numel():
+        raise ValueError("dy shape mismatch")
+    dz = torch.empty_like(z)
+    da = torch.empty_like(z) if p_drop > 0 else dz
+    dgamma = torch.empty(d, dtype=torch.float32, device=z.device)
+    dbeta = torch.empty(d, dtype=torch.float32, device=z.device)
+    partial = torch.empty(_PARTIAL_ROWS * 2 * d, dtype=torch.float32, device=z.device)
+    check(lib.mgx_ln_residual_bwd(_p(dy), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(da), _p(dgamma),
+                                  _p(dbeta), _p(partial), T, d, float(p_drop), seed, _dt(z), _stream()),
+          "mgx_ln_residual_bwd")
+    return dz, da, dgamma, dbeta
+
+
+# ---------------------------------------------------------------------------
+# bias + activation (+ dropout)
+# ---------------------------------------------------------------------------
+def bias_act_fwd(u, bias, act="gelu", p_drop=0.0, seed=0, inplace_pre=True):
+    """(pre, h) with pre = u + bias (written over u when inplace_pre) and h = dropout(act(pre))."""
+    _need(u, "u")
+    _need(bias, "bias", torch.float32)
+    n = u.shape[-1]
+    T = u.numel() // n
+    if bias.numel() != n:
+        raise ValueError("bias size mismatch")
+    pre = u if inplace_pre else torch.empty_like(u)
+    h = torch.empty_like(u)
+    check(lib.mgx_bias_act_fwd(_p(u), _p(bias), _p(pre), _p(h), T, n, _ACT[act], float(p_drop), seed, _dt(u), _stream()),
+          "mgx_bias_act_fwd")
+    return pre, h
+
+
+def bias_act_bwd(dh, pre, act="gelu", p_drop=0.0, seed=0):
+    _need(dh, "dh", pre.dtype)
+    n = pre.shape[-1]
+    T = pre.numel() // n
+    dpre = torch.empty_like(pre)
+    dbias = torch.empty(n, dtype=torch.float32, device=pre.device)
+    partial = torch.empty(_PARTIAL_ROWS * n, dtype=torch.float32, device=pre.device)
+    check(lib.mgx_bias_act_bwd(_p(dh), _p(pre), _p(dpre), _p(dbias), _p(partial), T, n, _ACT[act], float(p_drop), seed,
+                               _dt(pre), _stream()), "mgx_bias_act_bwd")
+    return dpre, dbias
+
+
+# ---------------------------------------------------------------------------
+# softmax cross-entropy
+# ---------------------------------------------------------------------------
+_XENT_SUMS = lib.mgx_xent_sums_len()
+
+
+class _SoftmaxXent(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, weight, ignore_index, col0, V):
+        _need(logits, "logits")
+        ld = logits.shape[-1]
+        T = logits.numel() // ld
+        tgt = targets.reshape(-1)
+        if tgt.dtype != torch.int64:
+            tgt = tgt.to(torch.int64)
+        tgt = tgt.contiguous()
+        _need(tgt, "targets", torch.int64)
+        if tgt.numel() != T:
+            raise ValueError(f"targets have {tgt.numel()} entries for {T} logit rows")
+        if weight is not None:
+            _need(weight, "weight", torch.float32)
+            if weight.numel() != V:
+                raise ValueError("class weight size mismatch")
+        dev = logits.device
+        row_loss = torch.empty(T, dtype=torch.float32, device=dev)
+        row_lse = torch.empty(T, dtype=torch.float32, device=dev)
+        sums = torch.empty(_XENT_SUMS, dtype=torch.float32, device=dev)
+        ii = -100 if ignore_index is None else int(ignore_index)
+        check(lib.mgx_softmax_xent_fwd(_p(logits), _p(tgt), _p(weight), _p(row_loss), _p(row_lse), _p(sums), T, V, ld,
+                                       col0, ii, _dt(logits), _stream()), "mgx_softmax_xent_fwd")
+        ctx.save_for_backward(logits, tgt, weight, row_lse, sums)
+        ctx.meta = (T, V, ld, col0, ii)
+        return sums[0] / sums[1]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        logits, tgt, weight, row_lse, sums = ctx.saved_tensors
+        T, V, ld, col0, ii = ctx.meta
+        g = gloss.reshape(1).to(torch.float32).contiguous()
+        # other column ranges of a shared logits buffer belong to other heads: start from zero
+        dlogits = torch.zeros_like(logits) if V != ld else torch.empty_like(logits)
+        check(lib.mgx_softmax_xent_bwd(_p(logits), _p(tgt), _p(weight), _p(row_lse), _p(sums), _p(g), _p(dlogits), T, V,
+                                       ld, col0, ii, _dt(logits), _stream()), "mgx_softmax_xent_bwd")
+        return dlogits, None, None, None, None, None
+
+
+def softmax_cross_entropy(logits, targets, weight=None, ignore_index=None, col0=0, V=None):
+    """Mean (weighted) CE of logits[..., col0:col0+V] against targets; fp32 scalar."""
+    V = logits.shape[-1] - col0 if V is None else V
+    return _SoftmaxXent.apply(logits, targets, weight, ignore_index, col0, V)
+
+
+# ---------------------------------------------------------------------------
+# final Norm (base_layers.py:36-41) as an autograd op
+# ---------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        xc = x.contiguous()
+        y, z, mean, rstd = ln_residual_fwd(xc, None, gamma, beta, eps)
+        ctx.save_for_backward(z, mean, rstd, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, mean, rstd, gamma = ctx.saved_tensors
+        dz, _, dg, db = ln_residual_bwd(dy.contiguous(), None, z, mean, rstd, gamma)
+        return dz, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+# ---------------------------------------------------------------------------
+# whole post-LN decoder block as one autograd node
+# ---------------------------------------------------------------------------
+class _DecoderBlock(torch.autograd.Function):
+    """alibi_unified.py:86-95 / relative_transformer.py:77-86.
+
+    Inputs: x [B,S,d] in the compute dtype; fp32 master parameters (autograd
+    leaves) and their compute-dtype shadows (same tensors in fp32 mode).
+    GEMMs are plain library calls (torch.mm/addmm -> hipBLASLt); everything
+    between them is a libmgx kernel.
+    """
+
+    @staticmethod
+    def forward(ctx, x, cfg, slopes, E_master, E,
+                wqkv_m, bqkv_m, wp_m, bp_m, w1_m, b1_m, w2_m, b2_m, g1, be1, g2, be2,
+                wqkv, bqkv, wp, bp, w1, w2, b2):
+        n_heads, act, p_drop, eps, training = cfg
+        B, S, d = x.shape
+        T = B * S
+        x2 = x.reshape(T, d)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        p = p_drop if training else 0.0
+        seed1 = new_seed() if p > 0 else 0
+        seed2 = new_seed() if p > 0 else 0
+        qkv = torch.addmm(bqkv, x2, wqkv).view(B, S, 3 * d)
+        if E is None:
+            a, lse = alibi_attn_fwd(qkv, slopes, n_heads)
+        else:
+            a, lse = rel_attn_fwd(qkv, E, n_heads)
+        a2 = a.view(T, d)
+        pr = torch.addmm(bp, a2, wp)
+        h1, z1, mean1, rstd1 = ln_residual_fwd(pr, x2, g1, be1, eps, p, seed1)
+        u = torch.mm(h1, w1.t())
+        pre, hact = bias_act_fwd(u, b1_m, act, p, seed2)
+        v = torch.addmm(b2, hact, w2.t())
+        h2, z2, mean2, rstd2 = ln_residual_fwd(v, h1, g2, be2, eps)
+        ctx.save_for_backward(x2, qkv, a, lse, z1, mean1, rstd1, h1, pre, hact, z2, mean2, rstd2,
+                              slopes, E, wqkv, wp, w1, w2, g1, g2)
+        ctx.cfg = (n_heads, act, p, seed1, seed2, B, S, d)
+        return h2.view(B, S, d)
+
+    @staticmethod
+    def backward(ctx, dh2):
+        (x2, qkv, a, lse, z1, mean1, rstd1, h1, pre, hact, z2, mean2, rstd2,
+         slopes, E, wqkv, wp, w1, w2, g1, g2) = ctx.saved_tensors
+        n_heads, act, p, seed1, seed2, B, S, d = ctx.cfg
+        T = B * S
+        f32 = torch.float32
+        dh2 = dh2.reshape(T, d).contiguous()
+        dz2, _, dg2, dbe2 = ln_residual_bwd(dh2, None, z2, mean2, rstd2, g2)
+        dw2 = torch.mm(dz2.t(), hact)                      # [d, ff]
+        db2 = dz2.sum(0, dtype=f32)
+        dact = torch.mm(dz2, w2)                           # [T, ff]
+        dpre, db1 = bias_act_bwd(dact, pre, act, p, seed2)
+        dw1 = torch.mm(dpre.t(), h1)                       # [ff, d]
+        dh1 = torch.mm(dpre, w1)                           # [T, d]
+        dz1, da1, dg1, dbe1 = ln_residual_bwd(dh1, dz2, z1, mean1, rstd1, g1, p, seed1)
+        a2 = a.view(T, d)
+        dwp = torch.mm(a2.t(), da1)                        # [d, d]
+        dbp = da1.sum(0, dtype=f32)
+        da = torch.mm(da1, wp.t()).view(B, S, d)
+        if E is None:
+            dqkv = alibi_attn_bwd(da, qkv, a, lse, slopes, n_heads)
+            dE = None
+        else:
+            dqkv, dE = rel_attn_bwd(da, qkv, a, lse, E, n_heads)
+        dqkv2 = dqkv.view(T, 3 * d)
+        dwqkv = torch.mm(x2.t(), dqkv2)                    # [d, 3d]
+        dbqkv = dqkv2.sum(0, dtype=f32)
+        dx = torch.addmm(dz1, dqkv2, wqkv.t()).view(B, S, d)
+        return (dx, None, None, dE, None,
+                dwqkv.unsqueeze(0), dbqkv, dwp.unsqueeze(0), dbp, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2,
+                None, None, None, None, None, None, None)
+
+
+def fused_decoder_block(x, n_heads, act, p_drop, eps, training, slopes, E_master, E,
+                        masters, shadows):
+    """masters: (c_attn.w, c_attn.b, c_proj.w, c_proj.b, linear1.weight, linear1.bias, linear2.weight,
+    linear2.bias, norm1.weight, norm1.bias, norm2.weight, norm2.bias) fp32 parameters.
+    shadows: (wqkv [d,3d], bqkv, wp [d,d], bp, w1 [ff,d], w2 [d,ff], b2) in the compute dtype."""
+    cfg = (n_heads, act, float(p_drop), float(eps), bool(training))
+    return _DecoderBlock.apply(x, cfg, slopes, E_master, E, *masters, *shadows)
+
+
+# ---------------------------------------------------------------------------
+# decode
+# ---------------------------------------------------------------------------
+def kv_append(qkv, kcache, vcache, pos0: int):
+    """qkv [B,R,3*d]; caches [B,H,Lmax,dh]."""
+    _need(qkv, "qkv")
+    _need(kcache, "kcache", qkv.dtype)
+    _need(vcache, "vcache", qkv.dtype)
+    B, R, d3 = qkv.shape
+    Bc, H, Lmax, dh = kcache.shape
+    if Bc != B or 3 * H * dh != d3 or vcache.shape != kcache.shape:
+        raise ValueError("kv_append shape mismatch")
+    check(lib.mgx_kv_append(_p(qkv), _p(kcache), _p(vcache), B, R, H, dh, Lmax, pos0, _dt(qkv), _stream()),
+          "mgx_kv_append")
+
+
+def decode_attn(q, kcache, vcache, slopes, pos0: int):
+    """q [B,R,H*dh] rows at absolute positions pos0..pos0+R-1 -> out [B,R,H*dh]."""
+    _need(q, "q")
+    _need(kcache, "kcache", q.dtype)
+    _need(vcache, "vcache", q.dtype)
+    B, R, d = q.shape
+    Bc, H, Lmax, dh = kcache.shape
+    if Bc != B or H * dh != d or vcache.shape != kcache.shape:
+        raise ValueError("decode_attn shape mismatch")
+    out = torch.empty_like(q)
+    check(lib.mgx_decode_attn(_p(q), _p(kcache), _p(vcache), _p(slopes), _p(out), B, R, H, dh, Lmax, pos0, _dt(q),
+                              _stream()), "mgx_decode_attn")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# optimizer
+# ---------------------------------------------------------------------------
+def adamw_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _need(param, "param", torch.float32)
+    _need(grad, "grad")
+    _need(exp_avg, "exp_avg", torch.float32)
+    _need(exp_avg_sq, "exp_avg_sq", torch.float32)
+    n = param.numel()
+    if grad.numel() != n or exp_avg.numel() != n or exp_avg_sq.numel() != n:
+        raise ValueError("adamw size mismatch")
+    if shadow is not None:
+        _need(shadow, "shadow", torch.bfloat16)
+        if shadow.numel() != n:
+            raise ValueError("shadow size mismatch")
+    check(lib.mgx_adamw(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(shadow), n, lr, beta1, beta2, eps,
+                        weight_decay, step, grad_scale, _dt(grad), _stream()), "mgx_adamw")

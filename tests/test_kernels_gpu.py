@@ -1,0 +1,306 @@
+"""GPU parity of each libmgx kernel (through the C ABI, via musicgeneration_amd.ops)
+against the CPU oracle on the same seeded inputs.
+
+Tolerances: fp32 kernels 1e-5 relative to the tensor's max magnitude (north_star);
+bf16 kernels 2e-2, measured against the fp32 oracle evaluated on the bf16-rounded inputs.
+"""
+import math
+
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import reference_port as O
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-5
+BF16_TOL = 2e-2
+
+
+def _ops():
+    from musicgeneration_amd import ops
+    return ops
+
+
+def _ref_attn(qkv, H, slopes=None, E=None, max_seq=None):
+    """oracle attention on packed qkv [B,S,3d] (fp32 CPU), returns [B,S,d]."""
+    B, S, d3 = qkv.shape
+    d = d3 // 3
+    q, k, v = (O._heads(t, H) for t in torch.split(qkv, d, dim=2))
+    if E is None and slopes is not None:
+        ramp = torch.arange(S, dtype=torch.float32)
+        mask = slopes.float()[:, None, None] * ramp[None, None, :] + O.causal_mask(S)[None]
+        out = O.alibi_attention(q, k, v, mask)
+    elif E is None:
+        out = O.alibi_attention(q, k, v, O.alibi_mask(S, H))
+    else:
+        out = O.relative_attention(q, k, v, E, max_seq, O.causal_mask(S))
+    return O._merge(out)
+
+
+ATTN_CASES = [  # B, S, H, dh
+    (2, 48, 8, 8), (1, 33, 6, 16), (2, 130, 4, 64), (1, 257, 2, 128), (1, 70, 3, 24),
+]
+
+
+@pytest.mark.parametrize("B,S,H,dh", ATTN_CASES)
+def test_alibi_attention_fp32(B, S, H, dh):
+    ops = _ops()
+    g = torch.Generator().manual_seed(S * 131 + dh)
+    qkv = torch.randn(B, S, 3 * H * dh, generator=g)
+    dout = torch.randn(B, S, H * dh, generator=g)
+    slopes = torch.tensor(O.alibi_slopes(H), dtype=torch.float32)
+    ref_in = qkv.clone().requires_grad_(True)
+    ref = _ref_attn(ref_in, H)
+    ref.backward(dout)
+    out, lse = ops.alibi_attn_fwd(qkv.cuda(), slopes.cuda(), H)
+    assert gu.rel_err(out, ref) < F32_TOL
+    dqkv = ops.alibi_attn_bwd(dout.cuda(), qkv.cuda(), out, lse, slopes.cuda(), H)
+    assert gu.rel_err(dqkv, ref_in.grad) < F32_TOL
+    # lse definition: log sum exp of q.k/sqrt(dh) + slope*(j-i)
+    q, k, _ = (O._heads(t, H) for t in torch.split(qkv, H * dh, dim=2))
+    s = q @ k.transpose(-1, -2) / math.sqrt(dh)
+    idx = torch.arange(S)
+    s = s + slopes[None, :, None, None] * (idx[None, :] - idx[:, None])[None, None] + O.causal_mask(S)
+    assert gu.rel_err(lse, torch.logsumexp(s, -1)) < F32_TOL
+
+
+@pytest.mark.parametrize("B,S,H,dh", [(2, 130, 4, 64), (1, 257, 2, 128), (2, 384, 2, 64), (1, 512, 8, 128),
+                                       (1, 100, 2, 16)])
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_alibi_attention_bf16(B, S, H, dh, force_generic):
+    ops = _ops()
+    from musicgeneration_amd._lib import lib
+    g = torch.Generator().manual_seed(S * 7 + dh)
+    qkv = torch.randn(B, S, 3 * H * dh, generator=g).bfloat16()
+    dout = torch.randn(B, S, H * dh, generator=g).bfloat16()
+    slopes = torch.tensor(O.alibi_slopes(H), dtype=torch.float32)
+    ref_in = qkv.float().requires_grad_(True)
+    ref = _ref_attn(ref_in, H)
+    ref.backward(dout.float())
+    lib.mgx_debug_force_generic_attention(1 if force_generic else 0)
+    try:
+        out, lse = ops.alibi_attn_fwd(qkv.cuda(), slopes.cuda(), H)
+        dqkv = ops.alibi_attn_bwd(dout.cuda(), qkv.cuda(), out, lse, slopes.cuda(), H)
+    finally:
+        lib.mgx_debug_force_generic_attention(0)
+    assert gu.rel_err(out.float(), ref) < BF16_TOL
+    assert gu.rel_err(dqkv.float(), ref_in.grad) < BF16_TOL
+
+
+def test_alibi_attention_bf16_asymmetric_exact():
+    """Integer-valued data with one-hot queries: any swapped fragment index in the
+    MFMA kernel shows up as an exact mismatch (guide: test maps with asymmetric data)."""
+    ops = _ops()
+    B, S, H, dh = 1, 192, 1, 64
+    q = torch.zeros(B, S, dh)
+    k = torch.zeros(B, S, dh)
+    v = torch.zeros(B, S, dh)
+    for i in range(S):
+        q[0, i, i % dh] = 8.0
+        k[0, i, (i * 7) % dh] = float((i % 5) - 2)
+        v[0, i] = torch.arange(dh) * 0.0625 + (i % 9)
+    qkv = torch.cat([q, k, v], -1).bfloat16()
+    slopes = torch.tensor([0.25])
+    ref = _ref_attn(qkv.float(), H, slopes=slopes)
+    out, _ = ops.alibi_attn_fwd(qkv.cuda(), slopes.cuda(), H)
+    assert gu.rel_err(out.float(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("B,S,H,dh,M", [(2, 40, 8, 8, 64), (1, 64, 4, 16, 64), (2, 150, 2, 64, 160)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_relative_attention(B, S, H, dh, M, dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(S + dh + M)
+    qkv = torch.randn(B, S, 3 * H * dh, generator=g).to(dtype)
+    E = (0.5 * torch.randn(H, M, dh, generator=g)).to(dtype)
+    dout = torch.randn(B, S, H * dh, generator=g).to(dtype)
+    ref_in = qkv.float().requires_grad_(True)
+    ref_E = E.float().requires_grad_(True)
+    ref = _ref_attn(ref_in, H, E=ref_E, max_seq=M)
+    ref.backward(dout.float())
+    out, lse = ops.rel_attn_fwd(qkv.cuda(), E.cuda(), H)
+    dqkv, dE = ops.rel_attn_bwd(dout.cuda(), qkv.cuda(), out, lse, E.cuda(), H)
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    assert gu.rel_err(out.float(), ref) < tol
+    assert gu.rel_err(dqkv.float(), ref_in.grad) < tol
+    assert gu.rel_err(dE, ref_E.grad) < tol
+
+
+@pytest.mark.parametrize("T,d", [(96, 64), (37, 96), (128, 512), (64, 1024), (20, 2048)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_layernorm_residual(T, d, dtype, with_res):
+    ops = _ops()
+    g = torch.Generator().manual_seed(T + d)
+    a = torch.randn(T, d, generator=g).to(dtype)
+    res = torch.randn(T, d, generator=g).to(dtype) if with_res else None
+    gamma = 1 + 0.1 * torch.randn(d, generator=g)
+    beta = 0.1 * torch.randn(d, generator=g)
+    dy = torch.randn(T, d, generator=g).to(dtype)
+    dy2 = torch.randn(T, d, generator=g).to(dtype)
+    a_r = a.float().requires_grad_(True)
+    gm = gamma.clone().requires_grad_(True)
+    bt = beta.clone().requires_grad_(True)
+    zin = a_r + (res.float() if with_res else 0)
+    if dtype == torch.bfloat16:
+        zin = zin + (zin.bfloat16().float() - zin).detach()     # the kernel normalises the stored (rounded) sum
+    ref = O.final_norm(zin, gm, bt)
+    ref.backward(dy.float() + dy2.float())
+    y, z, mean, rstd = ops.ln_residual_fwd(a.cuda(), None if res is None else res.cuda(), gamma.cuda(), beta.cuda())
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    assert gu.rel_err(y.float(), ref) < tol
+    dz, da, dg, db = ops.ln_residual_bwd(dy.cuda(), dy2.cuda(), z, mean, rstd, gamma.cuda())
+    assert da.data_ptr() == dz.data_ptr()
+    gtol = 2e-5 if dtype == torch.float32 else BF16_TOL
+    assert gu.rel_err(dz.float(), a_r.grad) < gtol
+    assert gu.rel_err(dg, gm.grad) < gtol
+    assert gu.rel_err(db, bt.grad) < gtol
+    # inference form: no saved tensors, same y
+    y2, z2, _, _ = ops.ln_residual_fwd(a.cuda(), None if res is None else res.cuda(), gamma.cuda(), beta.cuda(), save=False)
+    assert z2 is None
+    if dtype == torch.float32:
+        assert torch.equal(y2, y)
+
+
+def test_layernorm_dropout_mask_consistent():
+    """Dropout: forward and backward regenerate the same mask from (seed, index);
+    kept fraction ~ 1-p; kept elements scaled by 1/(1-p)."""
+    ops = _ops()
+    T, d, p, seed = 64, 512, 0.25, 1234567
+    a = torch.ones(T, d).cuda()
+    res = torch.zeros(T, d).cuda()
+    gamma, beta = torch.ones(d).cuda(), torch.zeros(d).cuda()
+    y, z, mean, rstd = ops.ln_residual_fwd(a, res, gamma, beta, 1e-5, p, seed)
+    kept = z > 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 0.02
+    assert torch.allclose(z[kept], torch.full_like(z[kept], 1 / (1 - p)))
+    dz, da, _, _ = ops.ln_residual_bwd(torch.randn(T, d).cuda(), None, z, mean, rstd, gamma, p, seed)
+    assert torch.equal(da != 0, kept & (dz != 0))
+    assert torch.allclose(da[kept], dz[kept] / (1 - p))
+
+
+@pytest.mark.parametrize("T,n", [(50, 128), (33, 4096), (257, 512)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["gelu", "relu"])
+def test_bias_act(T, n, dtype, act):
+    ops = _ops()
+    g = torch.Generator().manual_seed(T + n)
+    u = torch.randn(T, n, generator=g).to(dtype)
+    bias = 0.5 * torch.randn(n, generator=g)
+    dh = torch.randn(T, n, generator=g).to(dtype)
+    u_r = u.float().requires_grad_(True)
+    b_r = bias.clone().requires_grad_(True)
+    pre_ref = u_r + b_r
+    if dtype == torch.bfloat16:
+        pre_ref = pre_ref + (pre_ref.bfloat16().float() - pre_ref).detach()
+    ref = O._ACT[act](pre_ref)
+    ref.backward(dh.float())
+    pre, h = ops.bias_act_fwd(u.cuda().clone(), bias.cuda(), act, inplace_pre=False)
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    assert gu.rel_err(h.float(), ref) < tol
+    dpre, dbias = ops.bias_act_bwd(dh.cuda(), pre, act)
+    assert gu.rel_err(dpre.float(), u_r.grad) < tol
+    assert gu.rel_err(dbias, b_r.grad) < (2e-5 if dtype == torch.float32 else BF16_TOL)
+
+
+@pytest.mark.parametrize("T,V", [(96, 618), (40, 92), (300, 203), (5, 130)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_softmax_xent(T, V, dtype, weighted):
+    ops = _ops()
+    g = torch.Generator().manual_seed(T + V)
+    logits = (3 * torch.randn(T, V, generator=g)).to(dtype)
+    y = torch.randint(0, V, (T,), generator=g)
+    y[::7] = 1
+    y[3] = 2
+    w = None
+    if weighted:
+        w = torch.ones(V)
+        w[1], w[2] = 0.0, 0.05
+    ref_in = logits.float().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_in, y, w, ignore_index=-100 if weighted else 1)
+    (ref * 1.7).backward()
+    x = logits.cuda().requires_grad_(True)
+    loss = ops.softmax_cross_entropy(x, y.cuda(), None if w is None else w.cuda(), None if weighted else 1)
+    (loss * 1.7).backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-5 * abs(float(ref.detach()))
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    assert gu.rel_err(x.grad.float(), ref_in.grad) < tol
+
+
+def test_softmax_xent_column_slices():
+    """Three heads in one [T, 425] logits buffer (separated model layout)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    T = 64
+    logits = torch.randn(T, 425, generator=g)
+    ys = [torch.randint(0, v, (T,), generator=g) for v in (92, 130, 203)]
+    x = logits.cuda().requires_grad_(True)
+    ref_in = logits.clone().requires_grad_(True)
+    total, ref_total = 0, 0
+    for (c0, V), y in zip(((0, 92), (92, 130), (222, 203)), ys):
+        total = total + ops.softmax_cross_entropy(x, y.cuda(), None, 1, col0=c0, V=V)
+        ref_total = ref_total + torch.nn.functional.cross_entropy(ref_in[:, c0:c0 + V], y, ignore_index=1)
+    total.backward()
+    ref_total.backward()
+    assert abs(float(total) - float(ref_total)) < 1e-5 * abs(float(ref_total))
+    assert gu.rel_err(x.grad, ref_in.grad) < F32_TOL
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,dh,R,pos0", [(3, 8, 8, 3, 0), (2, 4, 16, 2, 37), (2, 8, 64, 3, 200), (1, 8, 128, 1, 511),
+                                           (2, 2, 128, 4, 300)])
+def test_decode_attention(dtype, B, H, dh, R, pos0):
+    """Rows pos0..pos0+R-1 against the cache == the same rows of full causal attention."""
+    ops = _ops()
+    L = pos0 + R
+    Lmax = L + 5
+    d = H * dh
+    g = torch.Generator().manual_seed(pos0 + dh)
+    qkv = torch.randn(B, L, 3 * d, generator=g).to(dtype)
+    slopes = torch.tensor(O.alibi_slopes(H), dtype=torch.float32)
+    ref = _ref_attn(qkv.float(), H)[:, pos0:]
+    kc = torch.zeros(B, H, Lmax, dh, dtype=dtype).cuda()
+    vc = torch.zeros_like(kc)
+    qkv_g = qkv.cuda()
+    if pos0 > 0:
+        ops.kv_append(qkv_g[:, :pos0].contiguous(), kc, vc, 0)
+    ops.kv_append(qkv_g[:, pos0:].contiguous(), kc, vc, pos0)
+    k_ref = O._heads(qkv[:, :, d:2 * d].float(), H)
+    assert torch.equal(kc[:, :, :L].float().cpu(), k_ref)
+    q = qkv_g[:, pos0:, :d].contiguous()
+    out = ops.decode_attn(q, kc, vc, slopes.cuda(), pos0)
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    assert gu.rel_err(out.float(), ref) < tol
+
+
+def test_adamw_matches_torch():
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    p0 = torch.randn(1000, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=1e-4)
+    p = p0.clone().cuda()
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    shadow = torch.empty(1000, dtype=torch.bfloat16).cuda()
+    for step in range(1, 4):
+        grad = torch.randn(1000, generator=g)
+        ref.grad = grad.clone()
+        opt.step()
+        ops.adamw_step(p, grad.cuda(), m, v, shadow, 1e-3, 0.9, 0.999, 1e-8, 1e-4, step)
+    assert float((p.cpu() - ref.detach()).abs().max()) < 1e-6
+    assert torch.equal(shadow, p.bfloat16())
+
+
+def test_bad_arguments_fail_loudly():
+    ops = _ops()
+    from musicgeneration_amd._lib import MgxError
+    with pytest.raises(RuntimeError):
+        ops.alibi_attn_fwd(torch.zeros(1, 4, 24), torch.ones(1), 1)            # CPU tensor: no fallback
+    with pytest.raises(MgxError):
+        ops.ln_residual_fwd(torch.zeros(4, 6).cuda(), None, torch.ones(6).cuda(), torch.zeros(6).cuda())  # d % 4
+    with pytest.raises(ValueError):
+        ops.alibi_attn_fwd(torch.zeros(1, 4, 25).cuda(), torch.ones(1).cuda(), 1)
