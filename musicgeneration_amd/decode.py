@@ -1,0 +1,112 @@
+"""KV-cached autoregressive sampling for the ALiBi models.
+
+Reproduces the reference loops bit-for-bit in their token semantics
+(model_baseline/inference_unified.py:12-21, inference_separated.py:18-28):
+the token written to position i is drawn from the logits at position i+1 of a
+causal forward over the whole buffer, whose positions i and i+1 still hold
+their previous (stale) contents.  Instead of L-2 full forwards (O(L^2)
+attention each) every step runs three token rows — position i-1 (final since
+the previous step: its K/V become permanent cache entries) and the two
+provisional rows i, i+1 — against a per-layer K/V cache [B,H,Lmax,dh] with the
+mgx_decode_attn kernel, and keeps the logits of row i+1.
+
+Decode is partitioned by batch only (replicas; no collective).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .base_layers import active_dtype
+
+
+class KVCacheDecoder:
+    """Row-wise inference engine over a musicgeneration_amd AlibiTransformer (unified or separated)."""
+
+    def __init__(self, model, batch: int, max_len: int, dtype=None):
+        self.model = model
+        self.dtype = dtype or active_dtype(model.compute_dtype)
+        p = next(model.parameters())
+        if not p.is_cuda:
+            raise RuntimeError("KVCacheDecoder needs the model on the GPU (no CPU fallback)")
+        self.device = p.device
+        H = model.heads
+        dh = model.d_model // H
+        self.batch, self.max_len = batch, max_len
+        self.caches = [(torch.zeros(batch, H, max_len, dh, dtype=self.dtype, device=self.device),
+                        torch.zeros(batch, H, max_len, dh, dtype=self.dtype, device=self.device))
+                       for _ in model.decoder_layers]
+
+    @torch.no_grad()
+    def rows(self, tokens: torch.Tensor, pos0: int) -> torch.Tensor:
+        """Run token rows at absolute positions pos0.. through every layer.
+
+        tokens: [B,R] (unified) or [B,3,R] (separated).  Their K/V are written
+        into the caches at pos0..pos0+R-1 (overwriting provisional entries).
+        R <= 4 uses the decode kernel; longer runs must start at pos0 == 0
+        (prefill with the flash kernel).  Returns head logits for all R rows.
+        """
+        m = self.model
+        dt = self.dtype
+        h = m.embed_tokens(tokens, dt)
+        B, R, d = h.shape
+        if pos0 + R > self.max_len:
+            raise ValueError("rows beyond the cache length")
+        if R > 4 and pos0 != 0:
+            raise ValueError("prefill (more than 4 rows) must start at position 0")
+        T = B * R
+        for layer, (kc, vc) in zip(m.decoder_layers, self.caches):
+            wqkv, bqkv, wp, bp, w1, w2, b2 = layer.shadows(dt)
+            x2 = h.reshape(T, d)
+            qkv = torch.addmm(bqkv, x2, wqkv).view(B, R, 3 * d)
+            ops.kv_append(qkv, kc, vc, pos0)
+            if R <= 4:
+                q = qkv[:, :, :d].contiguous()
+                a = ops.decode_attn(q, kc, vc, layer.attn.slopes, pos0)
+            else:
+                a, _ = ops.alibi_attn_fwd(qkv, layer.attn.slopes, layer.heads)
+            pr = torch.addmm(bp, a.view(T, d), wp)
+            h1, _, _, _ = ops.ln_residual_fwd(pr, x2, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps, save=False)
+            u = torch.mm(h1, w1.t())
+            _, hact = ops.bias_act_fwd(u, layer.linear1.bias, layer.activation)
+            v = torch.addmm(b2, hact, w2.t())
+            h2, _, _, _ = ops.ln_residual_fwd(v, h1, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps, save=False)
+            h = h2.view(B, R, d)
+        hn, _, _, _ = ops.ln_residual_fwd(h.reshape(T, d), None, m.norm.g, m.norm.b, m.norm.epsilon, save=False)
+        return m.head(hn.view(B, R, d))
+
+
+def _draw(logits_row: torch.Tensor, deterministic: bool) -> torch.Tensor:
+    if deterministic:
+        return torch.argmax(logits_row, -1)
+    return torch.multinomial(logits_row.float().softmax(-1), num_samples=1).squeeze(-1)
+
+
+@torch.no_grad()
+def sample_next_plus_one(model, seq: torch.Tensor, idx: int = 1, deterministic: bool = False,
+                         progress=None) -> torch.Tensor:
+    """KV-cached equivalent of the reference `inference` loops; mutates and returns `seq`.
+
+    seq [B,L] (unified) or [B,3,L] (separated), int32 or int64, on the GPU.
+    """
+    separated = seq.dim() == 3
+    L = seq.shape[-1]
+    B = seq.shape[0]
+    if idx < 1:
+        raise ValueError("idx must be >= 1 (position idx-1 must exist)")
+    dec = KVCacheDecoder(model, B, L)
+    sl = (lambda a, b: seq[:, :, a:b]) if separated else (lambda a, b: seq[:, a:b])
+    if idx >= 2:
+        # positions 0..idx-2 are final before the first step
+        dec.rows(sl(0, idx - 1), 0)                       # flash kernel when > 4 rows, decode kernel otherwise
+    steps = range(idx, L - 1)
+    if progress is not None:
+        steps = progress(steps)
+    for i in steps:
+        logits = dec.rows(sl(i - 1, i + 2), i - 1)        # rows i-1 (final), i, i+1 (provisional)
+        if separated:
+            r = torch.stack([_draw(h[:, 2], deterministic) for h in logits], -1)
+            seq[:, :, i] = r.to(seq.dtype)
+        else:
+            seq[:, i] = _draw(logits[:, 2], deterministic).to(seq.dtype)
+    return seq

@@ -1,0 +1,237 @@
+"""Training runtime with the reference's train_utils.py surface — training_loop,
+Logger, load_checkpoint, save_checkpoint / get_checkpoints /
+remove_extra_checkpoints, recursive_cast, log_scalars — re-designed so that the
+step does not stall the GPU:
+
+  * low precision is bf16 (no loss scaling); a disabled GradScaler's state is
+    still written under ``grad_scaler`` so checkpoints keep the reference's keys
+    (train_utils.py:204-214, including the ``optmizer`` typo);
+  * the NaN check (train_utils.py:168) and the logging argmax (:181-182) no longer
+    force a device->host sync every step: losses stay on the device and are read
+    back every ``sync_every`` steps;
+  * the per-step checkpoint-directory glob (:176) runs only after a save;
+  * the per-step eval forward (:184-193) is kept but optional via ``eval_every``;
+  * ray / wandb are optional: ``Logger`` is an in-process object whose
+    ``step.remote`` / ``log.remote`` keep the actor duck type;
+  * data parallel: pass ``ddp=GradientBucketer(model)`` (one process per GPU, RCCL).
+"""
+from __future__ import annotations
+
+import os
+import pathlib
+from typing import Optional
+
+import torch
+
+try:
+    import wandb  # noqa: F401
+except Exception:                       # offline images
+    wandb = None
+
+try:
+    from tqdm import tqdm
+except Exception:                       # pragma: no cover
+    def tqdm(it):
+        return it
+
+
+def log_scalars(log: dict, step: int, prefix: str):
+    """train_utils.py:13-15; a no-op without wandb."""
+    tagged = {f"{prefix}/{k}": v for k, v in log.items()}
+    if wandb is not None and getattr(wandb, "run", None) is not None:
+        wandb.log(tagged, step=step)
+    return tagged
+
+
+def get_checkpoints(folder="."):
+    """`<int>.tar` files under folder, oldest first by integer step (train_utils.py:22-30)."""
+    steps = sorted(int(p.name[:-4]) for p in pathlib.Path(folder).glob("**/*.tar") if p.name[:-4].isdigit())
+    return [os.path.join(folder, f"{s}.tar") for s in steps]
+
+
+def remove_extra_checkpoints(folder=".", keep=5):
+    """train_utils.py:17-20."""
+    past = get_checkpoints(folder)
+    for path in past[:max(len(past) - keep, 0)]:
+        os.remove(path)
+
+
+def save_checkpoint(state: dict, step: int, folder="."):
+    """train_utils.py:32-33."""
+    torch.save(state, os.path.join(folder, str(step) + ".tar"))
+
+
+def recursive_cast(nested_tensor, fn):
+    """Apply fn to every leaf of nested lists/tuples/dicts (train_utils.py:39-51)."""
+    if isinstance(nested_tensor, (list, tuple)):
+        return [recursive_cast(t, fn) for t in nested_tensor]
+    if isinstance(nested_tensor, dict):
+        return {k: recursive_cast(v, fn) for k, v in nested_tensor.items()}
+    return fn(nested_tensor)
+
+
+class _Remote:
+    """`obj.method.remote(...)` shim so in-process loggers satisfy the Ray actor duck type."""
+
+    def __init__(self, fn):
+        self._fn = fn
+
+    def __call__(self, *a, **k):
+        return self._fn(*a, **k)
+
+    def remote(self, *a, **k):
+        return self._fn(*a, **k)
+
+
+class Logger:
+    """In-process version of the reference's Ray Logger actor (train_utils.py:54-79)."""
+
+    def __init__(self, init_fn=None, metrics=None) -> None:
+        self.run = init_fn() if init_fn is not None else None
+        self.metrics = metrics
+        self.log_loss = {}
+        self.history = []
+        self.step = _Remote(self._step)
+        self.log = _Remote(self._log)
+
+    @classmethod
+    def remote(cls, *a, **k):
+        return cls(*a, **k)
+
+    def _step(self, pred, y, loss_dict):
+        if self.metrics is not None:
+            self.metrics.update(pred, y)
+        for k, v in loss_dict.items():
+            self.log_loss[k] = self.log_loss.get(k, 0.0) + float(v)
+
+    def _log(self, steps, steps_since_log, prefix="train"):
+        out = {k: v / steps_since_log for k, v in self.log_loss.items()}
+        if self.metrics is not None:
+            out.update(self.metrics.compute())
+            self.metrics.reset()
+        self.history.append((steps, log_scalars(out, steps, prefix)))
+        for k in self.log_loss:
+            self.log_loss[k] = 0.0
+
+
+def _checkpoint_state(model, optimizer, scaler, criterion, lr_scheduler, steps):
+    m = model.module if hasattr(model, "module") else model
+    sd = m.reference_state_dict() if hasattr(m, "reference_state_dict") else m.state_dict()
+    return {"model": sd, "optmizer": optimizer.state_dict(), "grad_scaler": scaler.state_dict(),
+            "criterion": criterion.state_dict(), "lr_scheduler": lr_scheduler.state_dict(), "steps": steps}
+
+
+def load_checkpoint(run_dir, model, criterion=None, optimizer=None, lr_scheduler=None):
+    """Latest `<step>.tar` into the given objects (train_utils.py:81-98); failures are
+    reported and swallowed, as in the reference.  Returns the stored step count or None."""
+    try:
+        checkpoints = get_checkpoints(run_dir)
+        print("loading from saved checkpoint:", checkpoints[-1])
+        state = torch.load(checkpoints[-1], map_location="cpu", weights_only=True)
+        model.load_state_dict(state["model"])
+        if optimizer is not None:
+            optimizer.load_state_dict(state["optmizer"])
+        if criterion is not None:
+            criterion.load_state_dict(state["criterion"])
+        if lr_scheduler is not None:
+            lr_scheduler.load_state_dict(state["lr_scheduler"])
+        return state.get("steps")
+    except Exception as e:
+        print("unable to load", e)
+        return None
+
+
+def training_loop(model, train_set, criterion, optimizer, lr_scheduler, logger, log_scalar_metric_step,
+                  checkpoint_step, epochs, batch_size, eval_set=None, eval_logger=None, run_dir=".",
+                  mixed_precision=False, ddp=None, sync_every=16, eval_every=1, keep_checkpoints=3,
+                  max_steps: Optional[int] = None):
+    """Same contract as the reference (train_utils.py:101-224):
+      train_set.get() -> (x, y) numpy or tensors; model(x) -> pred; criterion(pred, y) -> (loss, dict);
+      logger.step.remote(pred_argmax, y, loss_dict), logger.log.remote(steps, steps_since_log).
+    mixed_precision=True runs the model in bf16 (autocast); fp32 otherwise.
+    Returns the number of samples processed.
+    """
+    os.makedirs(run_dir, exist_ok=True)
+    scaler = torch.amp.GradScaler("cuda", enabled=False)      # bf16 needs no scaling; key kept for checkpoints
+    dev = next(model.parameters()).device
+    if dev.type != "cuda":
+        raise RuntimeError("training_loop needs the model on the GPU (no CPU fallback)")
+
+    steps = 0
+    try:
+        checkpoints = get_checkpoints(run_dir)
+        if checkpoints:
+            print("loading from saved checkpoint:", checkpoints[-1])
+            state = torch.load(checkpoints[-1], map_location="cpu", weights_only=True)
+            model.load_state_dict(state["model"])
+            optimizer.load_state_dict(state["optmizer"])
+            criterion.load_state_dict(state["criterion"])
+            lr_scheduler.load_state_dict(state["lr_scheduler"])
+            steps = state["steps"]          # the reference then resets this to 0 (train_utils.py:154); we resume
+    except Exception as e:
+        print("unable to load due to:", e)
+
+    steps_since_log = 0
+    steps_since_checkpoint = 0
+    to_dev = lambda t: (torch.from_numpy(t) if not torch.is_tensor(t) else t).to(dev, non_blocking=True)
+    pending = []                            # (pred_argmax, y, loss_dict) kept on the device until the next sync
+    it = 0
+
+    def flush():
+        for pa, yy, ld in pending:
+            vals = {k: float(v) for k, v in ld.items()}
+            if any(v != v for v in vals.values()):
+                raise AssertionError("NaN loss")        # train_utils.py:168, checked at the sync point
+            logger.step.remote(recursive_cast(pa, lambda t: t.cpu()), yy.cpu(), vals)
+        pending.clear()
+
+    for _ in range(epochs):
+        for _i in tqdm(range(len(train_set))):
+            data = train_set.get()
+            x, y = recursive_cast(data, to_dev)
+            model.train()
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(mixed_precision)):
+                pred = model(x)
+                total_loss, loss_dict = criterion(pred, y)
+            optimizer.zero_grad(set_to_none=True)
+            total_loss.backward()
+            if ddp is not None:
+                ddp.finish()
+            optimizer.step()
+
+            steps += batch_size
+            steps_since_log += batch_size
+            steps_since_checkpoint += batch_size
+            it += 1
+            pending.append((recursive_cast(pred, lambda t: t.detach().argmax(-1)), y,
+                            recursive_cast(loss_dict, lambda t: t.detach())))
+            if len(pending) >= sync_every:
+                flush()
+
+            if eval_set is not None and eval_logger is not None and it % eval_every == 0:
+                with torch.no_grad():
+                    model.eval()
+                    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(mixed_precision)):
+                        ex, ey = recursive_cast(eval_set.get(), to_dev)
+                        epred = model(ex)
+                    eval_logger.step.remote(recursive_cast(epred, lambda t: t.argmax(-1).cpu()), ey.cpu(), {})
+
+            if steps_since_log // log_scalar_metric_step > 0:
+                flush()
+                logger.log.remote(steps, steps_since_log)
+                if eval_logger is not None:
+                    eval_logger.log.remote(steps, steps_since_log, prefix="eval")
+                steps_since_log = 0
+
+            if steps_since_checkpoint // checkpoint_step > 0:
+                save_checkpoint(_checkpoint_state(model, optimizer, scaler, criterion, lr_scheduler, steps), steps, run_dir)
+                remove_extra_checkpoints(run_dir, keep=keep_checkpoints)
+                steps_since_checkpoint = 0
+            if max_steps is not None and it >= max_steps:
+                flush()
+                return steps
+        flush()
+        lr_scheduler.step()
+        save_checkpoint(_checkpoint_state(model, optimizer, scaler, criterion, lr_scheduler, steps), steps, run_dir)
+        remove_extra_checkpoints(run_dir, keep=keep_checkpoints)
+    return steps

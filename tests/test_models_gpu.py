@@ -1,0 +1,291 @@
+"""GPU parity of the drop-in modules (musicgeneration_amd) against the golden
+vectors the real reference produced, and against the CPU oracle.
+
+fp32: logits/loss/grads within 1e-5 (2e-5 for grads) relative to the tensor max.
+bf16: logits within 2e-2.  Greedy decode: token sequences bit-exact in fp32.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import reference_port as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _unified_model(z, sd, dtype=None, activation="gelu"):
+    from musicgeneration_amd.model_baseline.alibi_unified import AlibiTransformer
+    V, d, L, H, M, ff = (int(v) for v in z["cfg"])
+    m = AlibiTransformer(vocab=V, embed_dim=d, n_layers=L, n_heads=H, max_sequence=M, proj_forward=ff, dropout=0.0,
+                         activation=activation, dtype=dtype)
+    missing = m.load_state_dict(sd, strict=True)
+    return m.cuda()
+
+
+def _check_unified(name, seeded, activation="gelu"):
+    from musicgeneration_amd.model_baseline.alibi_unified import Criterion
+    z = gu.load(name)
+    sd = gu.seeded_state_dict(z) if seeded else gu.state_dict(z)
+    m = _unified_model(z, sd, activation=activation)
+    x, y = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["y"]).cuda()
+    m.train()
+    logits = m(x)
+    assert logits.dtype == torch.float32
+    assert gu.rel_err(logits, z["logits"]) < 1e-5
+    loss, ld = Criterion(1).cuda()(logits, y)
+    assert abs(float(loss.detach()) - float(z["loss"])) < 1e-5 * abs(float(z["loss"]))
+    loss.backward()
+    named = dict(m.named_parameters())
+    for k, g in gu.grads(z).items():
+        assert gu.rel_err(named[k].grad, g) < 2e-5, k
+
+
+@pytest.mark.parametrize("name", ["unified_tiny", "unified_heads6", "unified_heads12"])
+def test_unified_fp32_small(name):
+    _check_unified(name, False)
+
+
+def test_unified_fp32_relu():
+    _check_unified("unified_relu", False, activation="relu")
+
+
+@pytest.mark.parametrize("name", ["unified_dh64_s256", "unified_dh128_s256", "unified_dh64_s320_l2"])
+def test_unified_fp32_seeded(name):
+    _check_unified(name, True)
+
+
+@pytest.mark.parametrize("name", ["unified_dh64_s256", "unified_dh128_s256", "unified_dh64_s320_l2"])
+def test_unified_bf16(name):
+    """bf16 mode (MFMA flash attention for dh 64/128) within 2e-2 of the reference's fp32 logits."""
+    from musicgeneration_amd.model_baseline.alibi_unified import Criterion
+    z = gu.load(name)
+    m = _unified_model(z, gu.seeded_state_dict(z), dtype="bf16")
+    x, y = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["y"]).cuda()
+    logits = m(x)
+    assert logits.dtype == torch.bfloat16
+    assert gu.rel_err(logits.float(), z["logits"]) < 2e-2
+    loss, _ = Criterion(1).cuda()(logits, y)
+    assert abs(float(loss.detach()) - float(z["loss"])) < 2e-2 * abs(float(z["loss"]))
+    loss.backward()
+    named = dict(m.named_parameters())
+    for k, g in gu.grads(z).items():
+        assert named[k].grad.dtype == torch.float32
+        assert gu.rel_err(named[k].grad, g) < 6e-2, k      # gradients: looser, informational bound
+    # the autocast route selects bf16 as well
+    m32 = _unified_model(z, gu.seeded_state_dict(z))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert m32(x).dtype == torch.bfloat16
+
+
+def test_state_dict_keys_match_reference():
+    z = gu.load("unified_tiny")
+    ref_keys = {k[3:] for k in z.files if k.startswith("sd.")}
+    m = _unified_model(z, gu.state_dict(z))
+    assert set(m.state_dict().keys()) == ref_keys
+    # the reference's persistent mask buffer: accepted on load, re-created on request
+    sd = dict(m.state_dict())
+    sd["mask"] = torch.zeros(8, 64, 64)
+    m.load_state_dict(sd)
+    ref_sd = m.reference_state_dict()
+    assert torch.equal(ref_sd["mask"], O.alibi_mask(64, 8))
+
+
+def test_separated_fp32():
+    from musicgeneration_amd.model_baseline.alibi_separated import AlibiTransformer, Criterion
+    z = gu.load("separated_tiny")
+    m = AlibiTransformer(92, 130, 203, 16, 16, 32, 2, 8, 64, 128, dropout=0.0)
+    m.load_state_dict(gu.state_dict(z))
+    m = m.cuda()
+    crit = Criterion(92, 130, 203, {"loss_notes": 1, "loss_velocity": 0.5, "loss_duration": 2}).cuda()
+    assert sorted(crit.state_dict().keys()) == list(z["crit_state_keys"])
+    x, y = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["y"]).cuda()
+    preds = m(x)
+    assert isinstance(preds, tuple) and len(preds) == 3
+    for p, k in zip(preds, ("logit_n", "logit_v", "logit_d")):
+        assert gu.rel_err(p, z[k]) < 1e-5
+    loss, ld = crit(preds, y)
+    for k in ("loss", "loss_notes", "loss_velocity", "loss_duration"):
+        assert abs(float(ld[k].detach()) - float(z[k])) < 1e-5 * abs(float(z[k])), k
+    loss.backward()
+    named = dict(m.named_parameters())
+    for k, g in gu.grads(z).items():
+        assert gu.rel_err(named[k].grad, g) < 2e-5, k
+    # plain tuple of tensors (not the packed fast path) gives the same loss
+    loss2, _ = crit(tuple(p.detach().clone() for p in preds), y)
+    assert abs(float(loss2) - float(z["loss"])) < 1e-5 * abs(float(z["loss"]))
+
+
+@pytest.mark.parametrize("S", [48, 64])
+def test_relative_fp32(S):
+    from musicgeneration_amd.old_models.relative_transformer import RelativeTransformer
+    z = gu.load("relative_tiny")
+    m = RelativeTransformer(618, 64, 2, 8, 64, 128, dropout=0.0)
+    m.load_state_dict(gu.state_dict(z))
+    m = m.cuda()
+    x, y = torch.from_numpy(z[f"s{S}.x"]).cuda(), torch.from_numpy(z[f"s{S}.y"]).cuda()
+    logits = m(x)
+    assert gu.rel_err(logits, z[f"s{S}.logits"]) < 1e-5
+    loss = torch.nn.functional.cross_entropy(logits.reshape(-1, 618), y.reshape(-1))
+    loss.backward()
+    named = dict(m.named_parameters())
+    for k, g in gu.grads(z, f"s{S}.grad.").items():
+        assert gu.rel_err(named[k].grad, g) < 2e-5, k
+
+
+@pytest.mark.parametrize("dtype,tol", [(None, 1e-5), ("bf16", 2e-2)])
+def test_relative_seeded(dtype, tol):
+    from musicgeneration_amd.old_models.relative_transformer import RelativeTransformer
+    z = gu.load("relative_dh64_s320")
+    V, d, L, H, M, ff = (int(v) for v in z["cfg"])
+    m = RelativeTransformer(V, d, L, H, M, ff, dropout=0.0, dtype=dtype)
+    m.load_state_dict(gu.seeded_state_dict(z))
+    m = m.cuda()
+    x, y = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["y"]).cuda()
+    logits = m(x)
+    assert gu.rel_err(logits.float(), z["logits"]) < tol
+    if dtype is None:
+        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, V), y.reshape(-1))
+        loss.backward()
+        named = dict(m.named_parameters())
+        for k, g in gu.grads(z).items():
+            assert gu.rel_err(named[k].grad, g) < 2e-5, k
+
+
+def test_train_step_matches_reference():
+    """Three AdamW steps (train_utils.py:160-173 body) reproduce the reference's losses and weights;
+    both torch.optim.AdamW and the fused mgx AdamW."""
+    from musicgeneration_amd.model_baseline.alibi_unified import AlibiTransformer, Criterion
+    from musicgeneration_amd.optim import FusedAdamW
+    z = gu.load("unified_train3")
+    for opt_cls in (torch.optim.AdamW, FusedAdamW):
+        m = AlibiTransformer(vocab=618, embed_dim=64, n_layers=2, n_heads=8, max_sequence=64, proj_forward=128, dropout=0.0)
+        m.load_state_dict(gu.state_dict(z, "sd0."))
+        m = m.cuda()
+        crit = Criterion(1)
+        opt = opt_cls(m.parameters(), lr=1e-3, weight_decay=1e-4)
+        for step in range(3):
+            x = torch.from_numpy(z["x"][step]).cuda()
+            y = torch.roll(x, -1, dims=1)
+            y[:, -2:] = 1
+            m.train()
+            loss, _ = crit(m(x), y)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            assert abs(float(loss.detach()) - float(z["losses"][step])) < 1e-5 * float(z["losses"][step])
+        for k, v in gu.state_dict(z, "sd3.").items():
+            assert float((m.state_dict()[k].cpu() - v).abs().max()) < 2e-5, (opt_cls.__name__, k)
+
+
+def test_greedy_decode_bit_exact_unified():
+    """KV-cached decode (fp32) reproduces the reference loop's token sequences exactly,
+    including the i+1 quirk and the primer overwrite (inference_unified.py:12-21)."""
+    from musicgeneration_amd.model_baseline.alibi_unified import AlibiTransformer
+    from musicgeneration_amd.model_baseline.inference_unified import inference
+    z = gu.load("greedy_unified")
+    m = AlibiTransformer(vocab=618, embed_dim=64, n_layers=2, n_heads=8, max_sequence=64, proj_forward=128, dropout=0.0)
+    m.load_state_dict(gu.state_dict(z))
+    m = m.cuda().eval()
+    for idx in (1, 9):
+        seq = torch.from_numpy(z[f"idx{idx}.seq_in"].copy()).cuda()
+        out = inference(m, seq, idx=idx, deterministic=True)
+        assert out.data_ptr() == seq.data_ptr()
+        assert np.array_equal(out.cpu().numpy(), z[f"idx{idx}.seq_out"]), idx
+    for idx in (0, 9):
+        seq = torch.from_numpy(z[f"last{idx}.seq_in"].copy()).cuda()
+        out = m.inference(seq, idx=idx, deterministic=False)
+        assert np.array_equal(out.cpu().numpy(), z[f"last{idx}.seq_out"]), idx
+
+
+def test_greedy_decode_bit_exact_separated():
+    from musicgeneration_amd.model_baseline.alibi_separated import AlibiTransformer
+    from musicgeneration_amd.model_baseline.inference_separated import inference
+    z = gu.load("greedy_separated")
+    m = AlibiTransformer(92, 130, 203, 16, 16, 32, 2, 8, 64, 128, dropout=0.0)
+    m.load_state_dict(gu.state_dict(z))
+    m = m.cuda().eval()
+    for idx in (1, 9):
+        seq = torch.from_numpy(z[f"idx{idx}.seq_in"].copy()).cuda()
+        out = inference(m, seq, idx=idx, deterministic=True)
+        assert np.array_equal(out.cpu().numpy(), z[f"idx{idx}.seq_out"]), idx
+    seq = torch.from_numpy(z["last0.seq_in"].copy()).cuda()
+    assert np.array_equal(m.inference(seq, idx=0, deterministic=False).cpu().numpy(), z["last0.seq_out"])
+
+
+def test_decode_matches_full_forward_long():
+    """Size-independent property at a kernel-shaped config: cached decode logits == full-forward
+    logits at every step of a 300-token greedy continuation (d=512, dh=64, fp32), and the
+    generated sequence equals the oracle's full-recompute loop on the CPU for the first steps."""
+    from musicgeneration_amd.model_baseline.alibi_unified import AlibiTransformer
+    from musicgeneration_amd.decode import KVCacheDecoder, sample_next_plus_one
+    torch.manual_seed(3)
+    m = AlibiTransformer(vocab=618, embed_dim=512, n_layers=2, n_heads=8, max_sequence=512, proj_forward=1024,
+                         dropout=0.0).cuda().eval()
+    B, L = 2, 96
+    seq = torch.zeros(B, L, dtype=torch.int32).cuda()
+    seq[:, 1:17] = torch.randint(2, 618, (B, 16), generator=torch.Generator().manual_seed(4)).cuda().int()
+    ref_seq = seq.clone()
+    out = sample_next_plus_one(m, seq, idx=17, deterministic=True)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    ref = O.sample_next_plus_one(lambda s: O.unified_forward(sd, s, 8), ref_seq.cpu(), idx=17, deterministic=True)
+    assert torch.equal(out.cpu(), ref)
+    # provisional-row logits equal the full forward's rows
+    dec = KVCacheDecoder(m, B, L)
+    dec.rows(out[:, :40], 0)
+    part = dec.rows(out[:, 40:43], 40)
+    with torch.no_grad():
+        full = m(out[:, :43])
+    assert gu.rel_err(part, full[:, 40:43]) < 1e-5
+
+
+def test_training_loop_end_to_end(tmp_path):
+    """training_loop with the reference's signature: loss decreases on a repeating batch,
+    checkpoints carry the reference's keys ('optmizer', 'grad_scaler', model 'mask') and resume."""
+    from musicgeneration_amd.model_baseline.alibi_unified import AlibiTransformer, Criterion, Metrics
+    from musicgeneration_amd import train_utils as tu
+    from musicgeneration_amd.synthetic import SyntheticUnifiedDataset
+    torch.manual_seed(0)
+    m = AlibiTransformer(vocab=618, embed_dim=64, n_layers=2, n_heads=4, max_sequence=64, proj_forward=128, dropout=0.1).cuda()
+    crit = Criterion(1).cuda()
+    opt = torch.optim.AdamW(m.parameters(), lr=3e-3, weight_decay=1e-4)
+    sched = torch.optim.lr_scheduler.StepLR(opt, 50)
+
+    class Repeat:
+        def __init__(self):
+            self.b = SyntheticUnifiedDataset(4, 64, seed=5).get()
+        def __len__(self):
+            return 30
+        def get(self):
+            return tuple(t.cpu().numpy() for t in self.b)      # numpy, as the reference's Ray dataset yields
+
+    logger = tu.Logger(None, Metrics())
+    n = tu.training_loop(m, Repeat(), crit, opt, sched, logger, log_scalar_metric_step=40, checkpoint_step=60,
+                         epochs=1, batch_size=4, run_dir=str(tmp_path), mixed_precision=False, sync_every=4)
+    assert n == 120
+    losses = [h[1]["train/loss"] for h in logger.history]
+    assert len(losses) >= 2 and losses[-1] < losses[0]
+    assert "train/accuracy" in logger.history[0][1]
+    ck = tu.get_checkpoints(str(tmp_path))
+    assert ck and len(ck) <= 3
+    state = torch.load(ck[-1], map_location="cpu", weights_only=True)
+    assert set(state.keys()) == {"model", "optmizer", "grad_scaler", "criterion", "lr_scheduler", "steps"}
+    assert "mask" in state["model"] and state["model"]["mask"].shape == (4, 64, 64)
+    m2 = AlibiTransformer(vocab=618, embed_dim=64, n_layers=2, n_heads=4, max_sequence=64, proj_forward=128)
+    assert tu.load_checkpoint(str(tmp_path), m2) == state["steps"]
+    assert torch.equal(m2.state_dict()["embed.weight"], state["model"]["embed.weight"])
+
+
+def test_dropout_training_mode_runs_and_differs():
+    from musicgeneration_amd.model_baseline.alibi_unified import AlibiTransformer
+    torch.manual_seed(1)
+    m = AlibiTransformer(vocab=618, embed_dim=64, n_layers=1, n_heads=4, max_sequence=64, proj_forward=128, dropout=0.3).cuda()
+    x = torch.randint(0, 618, (2, 32)).cuda()
+    m.train()
+    a, b = m(x), m(x)
+    assert not torch.equal(a, b)
+    m.eval()
+    assert torch.equal(m(x), m(x))
+    m.train()
+    m(x).float().sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
