@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training tokens/s of the fused ALiBi transformer step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train_unified|train_separated|
+                     train_relative|decode_unified] [--batch B] [--seq S] [--dtype bf16|fp32]
+
+One "step" = one full training step (forward, fused softmax-CE, backward,
+gradient all-reduce when N>1, fused AdamW) on one batch of synthetic MIDI-grammar
+tokens already resident in HBM.  N=1 default workload = BASELINE.json configs[1]:
+alibi_unified d=1024 L=6 H=8 ff=4096 V=618, bf16, seq 2048, batch 16 per GPU.
+For N>1 launch under torch.distributed.run (one rank per GPU, RCCL); weak scaling.
+
+Rank 0 prints ONE JSON line with the metric, the roofline of the dominant libmgx
+kernel (HIP-event timed inside the timed region) and the CPU baseline (the
+oracle's restatement of the reference step on the host cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0         # HBM3E spec, same table
+
+
+def fwd_flops_per_token(L, d, ff, S, V, s_eff_factor=1.0):
+    """L*(2d*3d + 2d*d + 4d*ff + 2d*S_eff) + 2dV, causal attention at half the square."""
+    return L * (2 * d * 3 * d + 2 * d * d + 4 * d * ff + 2 * d * S * s_eff_factor) + 2 * d * V
+
+
+def build_workload(name, batch, seq, dtype, device):
+    from musicgeneration_amd.misc import EasyDict
+    from musicgeneration_amd.synthetic import SyntheticSeparatedDataset, SyntheticUnifiedDataset
+    rank = int(os.environ.get("RANK", "0"))
+    if name == "train_unified":
+        from musicgeneration_amd.model_baseline import build_everything_unified as cfg
+        args = cfg.m_args.get_copy()
+        args.max_sequence = max(seq, args.max_sequence)
+        args.dtype = dtype
+        model, crit = cfg.build_model_and_criterion(args)
+        data = SyntheticUnifiedDataset(batch, seq, seed=1234 + rank, device=device)
+        fl = fwd_flops_per_token(args.n_layers, args.embed_dim, args.proj_forward, seq, args.vocab)
+        desc = f"alibi_unified d={args.embed_dim} L={args.n_layers} H={args.n_heads} ff={args.proj_forward} V={args.vocab}"
+        lr, wd = cfg.opt_args.lr, cfg.opt_args.weight_decay
+        shape = (args.n_heads, args.embed_dim // args.n_heads, args.n_layers)
+    elif name == "train_separated":
+        from musicgeneration_amd.model_baseline import build_everything_separated as cfg
+        args = cfg.m_args.get_copy()
+        args.max_sequence = max(seq, args.max_sequence)
+        args.dtype = dtype
+        model, crit = cfg.build_model_and_criterion(args)
+        data = SyntheticSeparatedDataset(batch, seq, seed=1234 + rank, device=device)
+        d = args.embed_note + args.embed_velocity + args.embed_duration
+        fl = fwd_flops_per_token(args.n_layers, d, args.proj_forward, seq, 425)
+        desc = f"alibi_separated d={d} L={args.n_layers} H={args.n_heads} ff={args.proj_forward} V=92/130/203"
+        lr, wd = cfg.opt_args.lr, cfg.opt_args.weight_decay
+        shape = (args.n_heads, d // args.n_heads, args.n_layers)
+    elif name == "train_relative":
+        from musicgeneration_amd.old_models.relative_transformer import RelativeTransformer
+        model = RelativeTransformer(618, 512, 6, 8, max(seq, 4096), 2048, dropout=0.1, dtype=dtype)
+
+        class _CE(torch.nn.Module):
+            def forward(self, logits, y):
+                from musicgeneration_amd import ops
+                l = ops.softmax_cross_entropy(logits.contiguous(), y, None, None)
+                return l, {"loss": l}
+        crit = _CE()
+        data = SyntheticUnifiedDataset(batch, seq, seed=1234 + rank, device=device)
+        fl = fwd_flops_per_token(6, 512, 2048, seq, 618, 1.5)
+        desc = "relative_transformer d=512 L=6 H=8 ff=2048 V=618"
+        lr, wd = 1e-3, 1e-4
+        shape = (8, 64, 6)
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    return model.to(device), crit.to(device), data, fl, desc, lr, wd, shape
+
+
+def cpu_baseline(steps=3, warmup=1):
+    """the oracle (CPU restatement of the reference, parity-pinned by golden vectors)
+    runs config 1 — unified d=512 L=6 H=8 ff=4096, fp32, batch 8 x seq 1024, fwd+loss+bwd+AdamW."""
+    from oracle import reference_port as O
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(1234)
+    V, d, L, H, ff, B, S = 618, 512, 6, 8, 4096, 8, 1024
+    sd = {"embed.weight": torch.randn(V, d, generator=g), "norm.g": torch.ones(d), "norm.b": torch.zeros(d),
+          "proj_class.weight": torch.randn(V, d, generator=g) * d ** -0.5, "proj_class.bias": torch.zeros(V)}
+    for i in range(L):
+        p = f"decoder_layers.{i}."
+        sd.update({p + "attn.c_attn.w": 0.02 * torch.randn(1, d, 3 * d, generator=g), p + "attn.c_attn.b": torch.zeros(3 * d),
+                   p + "attn.c_proj.w": 0.02 * torch.randn(1, d, d, generator=g), p + "attn.c_proj.b": torch.zeros(d),
+                   p + "linear1.weight": torch.randn(ff, d, generator=g) * d ** -0.5, p + "linear1.bias": torch.zeros(ff),
+                   p + "linear2.weight": torch.randn(d, ff, generator=g) * ff ** -0.5, p + "linear2.bias": torch.zeros(d),
+                   p + "norm1.weight": torch.ones(d), p + "norm1.bias": torch.zeros(d),
+                   p + "norm2.weight": torch.ones(d), p + "norm2.bias": torch.zeros(d)})
+    sd = O.make_trainable(sd)
+    opt = torch.optim.AdamW(list(sd.values()), lr=1e-3, weight_decay=1e-4)
+    toks = O.synthetic_unified_tokens(B, S + 1, seed=1234)
+    x, y = toks[:, :-1], toks[:, 1:]
+    times = []
+    for it in range(warmup + steps):
+        t0 = time.perf_counter()
+        O.unified_train_step(sd, opt, x, y, H, pad_index=1)
+        if it >= warmup:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B * S / med, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"oracle fp32 train step, unified d=512 L=6 S=1024 batch 8 (configs[0]), {steps} timed steps "
+                      f"after {warmup} warm-up, median {med:.2f} s/step, dropout off"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="train_unified")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch")
+    ap.add_argument("--seq", type=int, default=None)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 "
+                             "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (musicgeneration_amd has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    if a.workload == "decode_unified":
+        return bench_decode(a, device, rank, world)
+
+    defaults = {"train_unified": (16, 2048), "train_separated": (8, 1024), "train_relative": (2, 4096)}[a.workload]
+    B = a.batch or defaults[0]
+    S = a.seq or defaults[1]
+    from musicgeneration_amd import ops
+    from musicgeneration_amd.optim import FusedAdamW
+    model, crit, data, fwd_fl, desc, lr, wd, (H, dh, L) = build_workload(a.workload, B, S, a.dtype, device)
+    opt = FusedAdamW(model.parameters(), lr=lr, weight_decay=wd)
+    ddp = None
+    if world > 1:
+        from musicgeneration_amd.data_parallel import GradientBucketer
+        ddp = GradientBucketer(model)
+    batches = [data.get() for _ in range(4)]          # resident in HBM before the timed region
+    model.train()
+
+    def step(i):
+        x, y = batches[i % len(batches)]
+        loss, _ = crit(model(x), y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if ddp is not None:
+            ddp.finish()
+        opt.step()
+        return loss
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.KERNEL_EVENTS = {}                             # HIP-event pairs around the roofline kernel's launches
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss.detach())
+
+    tokens = world * B * S * a.steps
+    value = tokens / dt
+    train_fl = 3 * fwd_fl
+    # roofline: attention forward kernel (one launch per layer per step)
+    roof = None
+    ev = events.get("alibi_attn_fwd") or events.get("rel_attn_fwd")
+    if ev:
+        ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
+        factor = 1.5 if a.workload == "train_relative" else 1.0
+        fl = 2.0 * B * H * S * S * dh * factor               # causal-algorithmic: QK^T + PV (+ QE^T) at half the square
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "attention forward (libmgx flash kernel)", "achieved": ach,
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                "launches_timed": len(ev), "avg_launch_ms": ms, "flops_per_launch": fl}
+    out = {
+        "metric": "training tokens/sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic MIDI-grammar tokens, random-init weights",
+        "config": {"workload": f"{a.workload}: {desc}, seq {S}, batch {B}/GPU, dropout 0.1, fused AdamW",
+                   "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
+        "step_tflops": value * train_fl / 1e12, "step_frac_of_bf16_peak": value * train_fl / 1e12 / PEAK_BF16_TFLOPS / world,
+        "final_loss": final_loss,
+        "roofline": roof,
+    }
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_decode(a, device, rank, world):
+    """configs[3]: KV-cached greedy sampling, unified d=1024 L=6, batch 64/GPU, 4096-token continuation
+    (shortened by --seq for quick runs).  Reports generated tokens/s; HBM roofline on the decode kernel."""
+    from musicgeneration_amd.model_baseline import build_everything_unified as cfg
+    from musicgeneration_amd.decode import sample_next_plus_one
+    from musicgeneration_amd import ops
+    B = a.batch or 64
+    new = a.seq or 4096
+    L = 64 + new + 1
+    args = cfg.m_args.get_copy()
+    args.max_sequence = L
+    args.dtype = a.dtype
+    model, _ = cfg.build_model_and_criterion(args)
+    model = model.to(device).eval()
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    seq = torch.zeros(B, L, dtype=torch.int32, device=device)
+    seq[:, 1:64] = torch.randint(2, 618, (B, 63), generator=g, device=device, dtype=torch.int32)
+    warm = seq[:, :80].clone()
+    sample_next_plus_one(model, warm, idx=64, deterministic=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ops.KERNEL_EVENTS = {}
+    t0 = time.perf_counter()
+    sample_next_plus_one(model, seq, idx=64, deterministic=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    steps = L - 1 - 64
+    value = world * B * steps / dt
+    esz = 2 if a.dtype == "bf16" else 4
+    d, Ln = args.embed_dim, args.n_layers
+    ev = events.get("decode_attn")
+    roof = None
+    if ev:
+        ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
+        mean_ctx = 64 + steps / 2
+        by = B * 2 * d * mean_ctx * esz                     # K and V rows of one layer, mean context
+        ach = by / (ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "decode_attn_kernel", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": ach / PEAK_HBM_GBS, "traffic": None, "launches_timed": len(ev), "avg_launch_ms": ms,
+                "bytes_per_launch": by}
+    out = {"metric": "decode tokens/sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": 16,
+           "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": a.dtype, "data": "synthetic primer, random-init weights",
+           "config": {"workload": f"decode_unified: alibi_unified d={d} L={Ln}, batch {B}/GPU, {steps}-token greedy "
+                                  f"continuation from a 63-token primer, KV cache", "global_batch": world * B,
+                      "seq_len": L, "parallelism": f"replicas{world}"},
+           "roofline": roof}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

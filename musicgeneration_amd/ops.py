@@ -45,6 +45,30 @@ def _need(t: torch.Tensor, name: str, dtype=None):
         raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
 
 
+# bench.py sets this to a dict to collect (start, end) HIP-event pairs around single-kernel launches
+KERNEL_EVENTS = None
+
+
+class _timed:
+    """Records a HIP-event pair on the current stream around one kernel launch when KERNEL_EVENTS is a dict."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if KERNEL_EVENTS is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if KERNEL_EVENTS is not None:
+            self.e.record()
+            KERNEL_EVENTS.setdefault(self.name, []).append((self.s, self.e))
+        return False
+
+
 def new_seed() -> int:
     """Dropout seed drawn from torch's CPU generator (no device sync)."""
     return int(torch.empty((), dtype=torch.int64).random_().item()) & ((1 << 62) - 1)
@@ -63,8 +87,9 @@ def alibi_attn_fwd(qkv: torch.Tensor, slopes: torch.Tensor, n_heads: int) -> Tup
         raise ValueError(f"bad attention shapes qkv={tuple(qkv.shape)} heads={n_heads} slopes={slopes.numel()}")
     out = torch.empty(B, S, d, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, n_heads, S, dtype=torch.float32, device=qkv.device)
-    check(lib.mgx_alibi_attn_fwd(_p(qkv), _p(slopes), _p(out), _p(lse), B, S, n_heads, d // n_heads, _dt(qkv), _stream()),
-          "mgx_alibi_attn_fwd")
+    with _timed("alibi_attn_fwd"):
+        check(lib.mgx_alibi_attn_fwd(_p(qkv), _p(slopes), _p(out), _p(lse), B, S, n_heads, d // n_heads, _dt(qkv),
+                                     _stream()), "mgx_alibi_attn_fwd")
     return out, lse
 
 
@@ -91,7 +116,9 @@ def rel_attn_fwd(qkv: torch.Tensor, E: torch.Tensor, n_heads: int):
         raise ValueError(f"bad relative attention shapes qkv={tuple(qkv.shape)} E={tuple(E.shape)}")
     out = torch.empty(B, S, d, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, S, dtype=torch.float32, device=qkv.device)
-    check(lib.mgx_rel_attn_fwd(_p(qkv), _p(E), _p(out), _p(lse), B, S, H, dh, M, _dt(qkv), _stream()), "mgx_rel_attn_fwd")
+    with _timed("rel_attn_fwd"):
+        check(lib.mgx_rel_attn_fwd(_p(qkv), _p(E), _p(out), _p(lse), B, S, H, dh, M, _dt(qkv), _stream()),
+              "mgx_rel_attn_fwd")
     return out, lse
 
 
@@ -370,8 +397,9 @@ def decode_attn(q, kcache, vcache, slopes, pos0: int):
     if Bc != B or H * dh != d or vcache.shape != kcache.shape:
         raise ValueError("decode_attn shape mismatch")
     out = torch.empty_like(q)
-    check(lib.mgx_decode_attn(_p(q), _p(kcache), _p(vcache), _p(slopes), _p(out), B, R, H, dh, Lmax, pos0, _dt(q),
-                              _stream()), "mgx_decode_attn")
+    with _timed("decode_attn"):
+        check(lib.mgx_decode_attn(_p(q), _p(kcache), _p(vcache), _p(slopes), _p(out), B, R, H, dh, Lmax, pos0, _dt(q),
+                                  _stream()), "mgx_decode_attn")
     return out
 
 
