@@ -247,6 +247,298 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const bf16_t* __r
     }
 }
 
+
+// ===========================================================================
+// backward
+// ===========================================================================
+// delta[b,h,i] = sum_d dout[b,i,h,d]*out[b,i,h,d]; one 16-byte chunk per lane, dh/8 lanes per head.
+template <int DH>
+__global__ __launch_bounds__(256) void attn_delta_mfma_kernel(const bf16_t* __restrict__ dout,
+                                                               const bf16_t* __restrict__ out,
+                                                               float* __restrict__ delta, long n_chunks, int S,
+                                                               int H) {
+    constexpr int LPH = DH / 8;
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    float s = 0.f;
+    if (c < n_chunks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(dout + c * 8);
+        const bf16x8 o = *reinterpret_cast<const bf16x8*>(out + c * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s = fmaf((float)a[k], (float)o[k], s);
+    }
+#pragma unroll
+    for (int o = 1; o < LPH; o <<= 1) s += __shfl_xor(s, o, 64);
+    if (c < n_chunks && (c % LPH) == 0) {
+        const long bh = c / LPH;                 // (b*S + i)*H + h
+        const int h = (int)(bh % H);
+        const long bi = bh / H;
+        const int i = (int)(bi % S);
+        const long b = bi / S;
+        delta[(b * H + h) * S + i] = s;
+    }
+}
+
+// dQ: query on the lane (as the forward).  Per 32-key block:
+//   S^T = K.Q^T (+bias)   dP^T = V.dO^T (-delta)   dS^T = P^T*(dP^T)*scale   dQ^T += K^T.dS^T
+template <int DH>
+__global__ __launch_bounds__(256, (DH == 128 ? 1 : 2)) void attn_bwd_dq_mfma_kernel(
+    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
+    const float* __restrict__ delta, const float* __restrict__ slopes, bf16_t* __restrict__ dqkv, int S, int H,
+    float c, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * Img<DH>::TILE_BYTES];
+    char* Ks = smem;
+    char* Vs = smem + Img<DH>::TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, h5 = lane >> 5;
+    const int qb = gridDim.x - 1 - blockIdx.x;
+    const int q0 = qb * 128, qw0 = q0 + 32 * w;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const long rs = 3L * H * DH;
+    const bf16_t* base = qkv + (long)b * S * rs + (long)h * DH;
+    const bf16_t* kp = base + (long)H * DH;
+    const bf16_t* vp = base + 2L * H * DH;
+    const bf16_t* gp = dout + (long)b * S * H * DH + (long)h * DH;
+    const LaneAddr<DH> la(lane);
+
+    const int qi = qw0 + l31;
+    const bool qok = qi < S;
+    bf16x8 qf[DH / 16], gf[DH / 16];
+#pragma unroll
+    for (int ks = 0; ks < DH / 16; ++ks) {
+        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        qf[ks] = qok ? *reinterpret_cast<const bf16x8*>(base + (long)qi * rs + ks * 16 + 8 * h5) : z;
+        gf[ks] = qok ? *reinterpret_cast<const bf16x8*>(gp + (long)qi * H * DH + ks * 16 + 8 * h5) : z;
+    }
+    const float lse2 = qok ? lse[((long)b * H + h) * S + qi] * LOG2E : INFINITY;
+    const float ndelta = qok ? -delta[((long)b * H + h) * S + qi] : 0.f;
+    const float sb = slopes[h] * LOG2E / c;
+
+    f32x16 dq[DH / 32];
+#pragma unroll
+    for (int d = 0; d < DH / 32; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+
+    const int kmax = min(q0 + 128, S);
+    const int ntiles = (kmax + 63) / 64;
+    TileRegs<DH> kr, vr;
+    tile_load<DH>(kr, kp, rs, 0, S, tid);
+    tile_load<DH>(vr, vp, rs, 0, S, tid);
+    for (int t = 0; t < ntiles; ++t) {
+        const int j0 = t * 64;
+        __syncthreads();
+        tile_store<DH>(kr, Ks, tid);
+        tile_store<DH>(vr, Vs, tid);
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            tile_load<DH>(kr, kp, rs, j0 + 64, S, tid);
+            tile_load<DH>(vr, vp, rs, j0 + 64, S, tid);
+        }
+        if (j0 <= qw0 + 31) {
+            const float lb = sb * (float)(j0 + 4 * h5 - qi);
+            const int dj = qi - j0 - 4 * h5;
+            const bool diag = j0 + 63 > qw0;
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                if (j0 + 32 * tb > qw0 + 31) continue;             // wave-uniform: block fully masked
+                f32x16 sc, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sc[r] = lb + sb * (float)(32 * tb + (r & 3) + 8 * (r >> 2));
+                    dp[r] = ndelta;
+                }
+#pragma unroll
+                for (int ks = 0; ks < DH / 16; ++ks) {
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(Ks + la.row_read(tb, ks)), qf[ks], sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(Vs + la.row_read(tb, ks)), gf[ks], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float p = exp2f(fmaf(sc[r], c, -lse2));
+                    if (diag && (32 * tb + (r & 3) + 8 * (r >> 2) > dj)) p = 0.f;
+                    sc[r] = p * dp[r] * scale;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 dsf = pack8(sc, 8 * s2);
+#pragma unroll
+                    for (int d = 0; d < DH / 32; ++d) {
+                        const bf16x8 kt = lds_read_tr_pair(Ks + la.tr_read(tb, s2, 0, d), Ks + la.tr_read(tb, s2, 1, d));
+                        dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, dsf, dq[d], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (qok) {
+        bf16_t* op = dqkv + ((long)b * S + qi) * rs + (long)h * DH;
+#pragma unroll
+        for (int d = 0; d < DH / 32; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = (bf16_t)dq[d][4 * g + k];
+                *reinterpret_cast<bf16x4*>(op + 32 * d + 8 * g + 4 * h5) = v;
+            }
+    }
+}
+
+// dK, dV: key on the lane.  Per 32-query block of a 64-query tile:
+//   S = Q.K^T (+bias-lse)  dP = dO.V^T (-delta)  P = exp2, dS = P*dP*scale
+//   dV^T += dO^T.P         dK^T += Q^T.dS        (P, dS straight from the accumulators)
+template <int DH>
+__global__ __launch_bounds__(256, (DH == 128 ? 1 : 2)) void attn_bwd_dkv_mfma_kernel(
+    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
+    const float* __restrict__ delta, const float* __restrict__ slopes, bf16_t* __restrict__ dqkv, int S, int H,
+    float c, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * Img<DH>::TILE_BYTES + 2 * 64 * sizeof(float)];
+    char* Qs = smem;
+    char* Gs = smem + Img<DH>::TILE_BYTES;
+    float* Ls = reinterpret_cast<float*>(smem + 2 * Img<DH>::TILE_BYTES);
+    float* Dn = Ls + 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, h5 = lane >> 5;
+    const int jb0 = blockIdx.x * 128, jw0 = jb0 + 32 * w;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const long rs = 3L * H * DH;
+    const bf16_t* base = qkv + (long)b * S * rs + (long)h * DH;
+    const bf16_t* kp = base + (long)H * DH;
+    const bf16_t* vp = base + 2L * H * DH;
+    const bf16_t* gp = dout + (long)b * S * H * DH + (long)h * DH;
+    const float* lse_bh = lse + ((long)b * H + h) * S;
+    const float* delta_bh = delta + ((long)b * H + h) * S;
+    const LaneAddr<DH> la(lane);
+
+    const int j = jw0 + l31;
+    const bool jok = j < S;
+    bf16x8 kf[DH / 16], vf[DH / 16];
+#pragma unroll
+    for (int ks = 0; ks < DH / 16; ++ks) {
+        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        kf[ks] = jok ? *reinterpret_cast<const bf16x8*>(kp + (long)j * rs + ks * 16 + 8 * h5) : z;
+        vf[ks] = jok ? *reinterpret_cast<const bf16x8*>(vp + (long)j * rs + ks * 16 + 8 * h5) : z;
+    }
+    const float sb = slopes[h] * LOG2E / c;
+    const float inv_c = 1.f / c;
+
+    f32x16 dk[DH / 32], dv[DH / 32];
+#pragma unroll
+    for (int d = 0; d < DH / 32; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[d][r] = dv[d][r] = 0.f;
+
+    const int t0 = jb0 / 64;
+    const int ntiles = (S + 63) / 64;
+    TileRegs<DH> qr, gr;
+    float r_lse = 0.f, r_delta = 0.f;
+    tile_load<DH>(qr, base, rs, t0 * 64, S, tid);
+    tile_load<DH>(gr, gp, (long)H * DH, t0 * 64, S, tid);
+    if (tid < 64 && t0 * 64 + tid < S) {
+        r_lse = lse_bh[t0 * 64 + tid];
+        r_delta = delta_bh[t0 * 64 + tid];
+    }
+    for (int t = t0; t < ntiles; ++t) {
+        const int i0 = t * 64;
+        __syncthreads();
+        tile_store<DH>(qr, Qs, tid);
+        tile_store<DH>(gr, Gs, tid);
+        if (tid < 64) {
+            const bool ok = i0 + tid < S;
+            Ls[tid] = ok ? -(sb * (float)tid + r_lse * LOG2E * inv_c) : -INFINITY;
+            Dn[tid] = ok ? -r_delta : 0.f;
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            tile_load<DH>(qr, base, rs, i0 + 64, S, tid);
+            tile_load<DH>(gr, gp, (long)H * DH, i0 + 64, S, tid);
+            if (tid < 64 && i0 + 64 + tid < S) {
+                r_lse = lse_bh[i0 + 64 + tid];
+                r_delta = delta_bh[i0 + 64 + tid];
+            }
+        }
+        if (i0 + 63 >= jw0) {                                      // wave-uniform
+            const float cj = sb * (float)(j - i0);
+            const bool diag = i0 < jw0 + 31;
+            const int di = j - i0 - 4 * h5;                        // masked when row-part < di
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                if (i0 + 32 * tb + 31 < jw0) continue;             // block entirely above the diagonal
+                f32x16 sc, dp;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 lv = *reinterpret_cast<const f32x4*>(Ls + 32 * tb + 8 * g + 4 * h5);
+                    const f32x4 dn = *reinterpret_cast<const f32x4*>(Dn + 32 * tb + 8 * g + 4 * h5);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        sc[4 * g + k] = cj + lv[k];
+                        dp[4 * g + k] = dn[k];
+                    }
+                }
+#pragma unroll
+                for (int ks = 0; ks < DH / 16; ++ks) {
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(Qs + la.row_read(tb, ks)), kf[ks], sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(Gs + la.row_read(tb, ks)), vf[ks], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float p = exp2f(sc[r] * c);
+                    if (diag && (32 * tb + (r & 3) + 8 * (r >> 2) < di)) p = 0.f;
+                    sc[r] = p;
+                    dp[r] = p * dp[r] * scale;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 pf = pack8(sc, 8 * s2);
+                    const bf16x8 dsf = pack8(dp, 8 * s2);
+#pragma unroll
+                    for (int d = 0; d < DH / 32; ++d) {
+                        const bf16x8 gt = lds_read_tr_pair(Gs + la.tr_read(tb, s2, 0, d), Gs + la.tr_read(tb, s2, 1, d));
+                        dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pf, dv[d], 0, 0, 0);
+                        const bf16x8 qt = lds_read_tr_pair(Qs + la.tr_read(tb, s2, 0, d), Qs + la.tr_read(tb, s2, 1, d));
+                        dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, dsf, dk[d], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (jok) {
+        bf16_t* op = dqkv + ((long)b * S + j) * rs + (long)h * DH;
+#pragma unroll
+        for (int d = 0; d < DH / 32; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 a, v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a[k] = (bf16_t)dk[d][4 * g + k];
+                    v[k] = (bf16_t)dv[d][4 * g + k];
+                }
+                *reinterpret_cast<bf16x4*>(op + (long)H * DH + 32 * d + 8 * g + 4 * h5) = a;
+                *reinterpret_cast<bf16x4*>(op + 2L * H * DH + 32 * d + 8 * g + 4 * h5) = v;
+            }
+    }
+}
+
+template <int DH>
+int launch_bwd_mfma(const void* dout, const void* qkv, const void* out, const float* lse, const float* slopes,
+                    void* dqkv, float* delta, int B, int S, int H, hipStream_t st) {
+    const float scale = 1.0f / sqrtf((float)DH);
+    const float c = LOG2E * scale;
+    const long n_chunks = (long)B * S * H * (DH / 8);
+    hipLaunchKernelGGL((attn_delta_mfma_kernel<DH>), dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st,
+                       (const bf16_t*)dout, (const bf16_t*)out, delta, n_chunks, S, H);
+    MGX_CHECK_LAUNCH("attn_delta_mfma");
+    dim3 grid((S + 127) / 128, H, B);
+    hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<DH>), grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)qkv,
+                       lse, delta, slopes, (bf16_t*)dqkv, S, H, c, scale);
+    MGX_CHECK_LAUNCH("attn_bwd_dkv_mfma");
+    hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DH>), grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)qkv,
+                       lse, delta, slopes, (bf16_t*)dqkv, S, H, c, scale);
+    MGX_CHECK_LAUNCH("attn_bwd_dq_mfma");
+    return MGX_OK;
+}
+
 }  // namespace
 
 bool mgx_attn_mfma_supported(int mode, int dh, int dtype) {
@@ -270,14 +562,13 @@ int mgx_attn_fwd_mfma(int mode, const void* qkv, const float* slopes, const void
     return MGX_OK;
 }
 
-int mgx_attn_bwd_generic(int mode, const void* dout, const void* qkv, const void* out, const float* lse,
-                         const float* slopes, const void* E, void* dqkv, float* dE, float* delta, int B, int S, int H,
-                         int dh, int max_seq, int dtype, hipStream_t st);
-
 int mgx_attn_bwd_mfma(int mode, const void* dout, const void* qkv, const void* out, const float* lse,
                       const float* slopes, const void* E, void* dqkv, float* dE, float* delta, int B, int S, int H,
                       int dh, int max_seq, hipStream_t st) {
-    // TODO(round 1, next step): MFMA backward; until then the generic kernels serve bf16 too.
-    return mgx_attn_bwd_generic(mode, dout, qkv, out, lse, slopes, E, dqkv, dE, delta, B, S, H, dh, max_seq, MGX_BF16,
-                                st);
+    (void)E;
+    (void)dE;
+    (void)max_seq;
+    MGX_REQUIRE(mode == 0, MGX_EUNSUPPORTED, "mgx_attn_bwd_mfma: mode %d", mode);
+    if (dh == 64) return launch_bwd_mfma<64>(dout, qkv, out, lse, slopes, dqkv, delta, B, S, H, st);
+    return launch_bwd_mfma<128>(dout, qkv, out, lse, slopes, dqkv, delta, B, S, H, st);
 }
