@@ -23,6 +23,7 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
+constexpr float RESCALE_LOG2 = 8.0f;
 
 template <int DH>
 struct Img {
@@ -33,6 +34,9 @@ struct Img {
         return G8 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
     }
 };
+
+// v_exp_f32 directly: arguments here are <= ~0 (or -inf); no denormal-range fix-up needed
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ bf16x8 lds_read16(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
@@ -72,15 +76,17 @@ struct TileRegs {
     bf16x8 v[DH / 32];
 };
 
+// Rows past the end are clamped to row S-1 instead of zero-filled: every consumer multiplies them
+// by an exactly-zero probability (causal mask / -inf row statistic), so real finite data is as good
+// as zeros and the load needs no branch.  Offsets are 32-bit (launchers check S*row_bytes < 2^31).
 template <int DH>
-__device__ __forceinline__ void tile_load(TileRegs<DH>& t, const bf16_t* src, long rs, int r0, int S, int tid) {
+__device__ __forceinline__ void tile_load(TileRegs<DH>& t, const bf16_t* src, unsigned rs, int r0, int S, int tid) {
 #pragma unroll
     for (int n = 0; n < DH / 32; ++n) {
         const int e = tid + 256 * n;
         const int row = e / Img<DH>::CPR, ch = e % Img<DH>::CPR;
-        const int g = r0 + row;
-        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        t.v[n] = (g < S) ? *reinterpret_cast<const bf16x8*>(src + (long)g * rs + ch * 8) : z;
+        const unsigned g = (unsigned)min(r0 + row, S - 1);
+        t.v[n] = *reinterpret_cast<const bf16x8*>(src + (g * rs + (unsigned)(ch * 8)));
     }
 }
 template <int DH>
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const bf16_t* __r
     const int qb = gridDim.x - 1 - blockIdx.x;          // heaviest (latest) query blocks first
     const int q0 = qb * 128, qw0 = q0 + 32 * w;
     const int b = blockIdx.z, h = blockIdx.y;
-    const long rs = 3L * H * DH;
+    const unsigned rs = 3u * H * DH;
     const bf16_t* base = qkv + (long)b * S * rs + (long)h * DH;
     const bf16_t* kp = base + (long)H * DH;
     const bf16_t* vp = base + 2L * H * DH;
@@ -199,24 +205,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const bf16_t* __r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[tb][r]);
             mx = half_swap_max(mx);
-            const float mn = fmaxf(m, mx);
-            const float alpha = exp2f((m - mn) * c);
-            const float mc = mn * c;
-            m = mn;
+            // Deferred rescale (T13): keep the stale running max while no row's max grew by more
+            // than 2^RESCALE_LOG2; P is then bounded by 2^RESCALE_LOG2 instead of 1 (fp32 sums,
+            // bf16 P keep their relative precision).  The decision is wave-uniform and taken
+            // before this tile's P is formed, with the previous tile's P.V already accumulated.
+            if (!__all((mx - m) * c <= RESCALE_LOG2)) {
+                const float mn = fmaxf(m, mx);
+                const float alpha = fast_exp2((m - mn) * c);
+                m = mn;
+                l *= alpha;
+#pragma unroll
+                for (int d = 0; d < DH / 32; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            }
+            const float mc = m * c;
             float psum = 0.f;
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = exp2f(fmaf(s[tb][r], c, -mc));
+                    const float p = fast_exp2(fmaf(s[tb][r], c, -mc));
                     s[tb][r] = p;
                     psum += p;
                 }
-            l = fmaf(l, alpha, psum);
-#pragma unroll
-            for (int d = 0; d < DH / 32; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            l += psum;
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
@@ -293,7 +306,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 1 : 2)) void attn_bwd_dq_mfma_ker
     const int qb = gridDim.x - 1 - blockIdx.x;
     const int q0 = qb * 128, qw0 = q0 + 32 * w;
     const int b = blockIdx.z, h = blockIdx.y;
-    const long rs = 3L * H * DH;
+    const unsigned rs = 3u * H * DH;
     const bf16_t* base = qkv + (long)b * S * rs + (long)h * DH;
     const bf16_t* kp = base + (long)H * DH;
     const bf16_t* vp = base + 2L * H * DH;
@@ -354,7 +367,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 1 : 2)) void attn_bwd_dq_mfma_ker
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float p = exp2f(fmaf(sc[r], c, -lse2));
+                    float p = fast_exp2(fmaf(sc[r], c, -lse2));
                     if (diag && (32 * tb + (r & 3) + 8 * (r >> 2) > dj)) p = 0.f;
                     sc[r] = p * dp[r] * scale;
                 }
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 1 : 2)) void attn_bwd_dkv_mfma_ke
     const int l31 = lane & 31, h5 = lane >> 5;
     const int jb0 = blockIdx.x * 128, jw0 = jb0 + 32 * w;
     const int b = blockIdx.z, h = blockIdx.y;
-    const long rs = 3L * H * DH;
+    const unsigned rs = 3u * H * DH;
     const bf16_t* base = qkv + (long)b * S * rs + (long)h * DH;
     const bf16_t* kp = base + (long)H * DH;
     const bf16_t* vp = base + 2L * H * DH;
@@ -433,7 +446,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 1 : 2)) void attn_bwd_dkv_mfma_ke
     TileRegs<DH> qr, gr;
     float r_lse = 0.f, r_delta = 0.f;
     tile_load<DH>(qr, base, rs, t0 * 64, S, tid);
-    tile_load<DH>(gr, gp, (long)H * DH, t0 * 64, S, tid);
+    tile_load<DH>(gr, gp, (unsigned)(H * DH), t0 * 64, S, tid);
     if (tid < 64 && t0 * 64 + tid < S) {
         r_lse = lse_bh[t0 * 64 + tid];
         r_delta = delta_bh[t0 * 64 + tid];
@@ -451,7 +464,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 1 : 2)) void attn_bwd_dkv_mfma_ke
         __syncthreads();
         if (t + 1 < ntiles) {
             tile_load<DH>(qr, base, rs, i0 + 64, S, tid);
-            tile_load<DH>(gr, gp, (long)H * DH, i0 + 64, S, tid);
+            tile_load<DH>(gr, gp, (unsigned)(H * DH), i0 + 64, S, tid);
             if (tid < 64 && i0 + 64 + tid < S) {
                 r_lse = lse_bh[i0 + 64 + tid];
                 r_delta = delta_bh[i0 + 64 + tid];
@@ -482,7 +495,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 1 : 2)) void attn_bwd_dkv_mfma_ke
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float p = exp2f(sc[r] * c);
+                    float p = fast_exp2(sc[r] * c);
                     if (diag && (32 * tb + (r & 3) + 8 * (r >> 2) < di)) p = 0.f;
                     sc[r] = p;
                     dp[r] = p * dp[r] * scale;
@@ -541,8 +554,9 @@ int launch_bwd_mfma(const void* dout, const void* qkv, const void* out, const fl
 
 }  // namespace
 
-bool mgx_attn_mfma_supported(int mode, int dh, int dtype) {
-    return mode == 0 && dtype == MGX_BF16 && (dh == 64 || dh == 128);
+bool mgx_attn_mfma_supported(int mode, int dh, int dtype, int S, int H) {
+    // 32-bit byte offsets inside one batch element: S * (3*H*dh) * 2 bytes must stay below 2^31
+    return mode == 0 && dtype == MGX_BF16 && (dh == 64 || dh == 128) && (long)S * 3 * H * dh * 2 < (1L << 31);
 }
 
 int mgx_attn_fwd_mfma(int mode, const void* qkv, const float* slopes, const void* E, void* out, float* lse, int B,

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ a, co
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= T_rows) return;
-    const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const unsigned thr16 = mgx_drop_thr16(p_drop);
+    const float keep_scale = mgx_keep_scale(thr16);
     float v[NV][N];
     float sum = 0.f;
 #pragma unroll
@@ -59,8 +60,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ a, co
             load_vec<T, N>(a + row * d + col, v[c]);
             if (p_drop > 0.f) {
 #pragma unroll
-                for (int k = 0; k < N; ++k)
-                    v[c][k] = mgx_uniform(seed, (unsigned long long)(row * d + col + k)) >= p_drop ? v[c][k] * keep_scale : 0.f;
+                for (int k = 0; k < N; k += 2) {
+                    bool k0, k1;
+                    mgx_keep_pair(seed, (unsigned long long)(row * d + col + k), thr16, k0, k1);
+                    v[c][k] = k0 ? v[c][k] * keep_scale : 0.f;
+                    v[c][k + 1] = k1 ? v[c][k + 1] * keep_scale : 0.f;
+                }
             }
             if (res) {
                 float r[N];
@@ -125,7 +130,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     constexpr int N = Vec<T>::N;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][2][d]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const unsigned thr16 = mgx_drop_thr16(p_drop);
+    const float keep_scale = mgx_keep_scale(thr16);
     float g_acc[NV][N], b_acc[NV][N];
 #pragma unroll
     for (int c = 0; c < NV; ++c)
@@ -173,8 +179,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 if (da && (da != dz || p_drop > 0.f)) {
                     if (p_drop > 0.f) {
 #pragma unroll
-                        for (int k = 0; k < N; ++k)
-                            o[k] = mgx_uniform(seed, (unsigned long long)(row * d + col + k)) >= p_drop ? o[k] * keep_scale : 0.f;
+                        for (int k = 0; k < N; k += 2) {
+                            bool k0, k1;
+                            mgx_keep_pair(seed, (unsigned long long)(row * d + col + k), thr16, k0, k1);
+                            o[k] = k0 ? o[k] * keep_scale : 0.f;
+                            o[k + 1] = k1 ? o[k + 1] * keep_scale : 0.f;
+                        }
                     }
                     store_vec<T, N>(da + row * d + col, o);
                 }
@@ -202,27 +212,63 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 }
 
 // out0[c] = sum_r partial[r][0][c]; out1[c] = sum_r partial[r][1][c]   (nseg = 1 or 2)
-__global__ void column_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out0,
-                                     float* __restrict__ out1, int nblk, int d, int nseg) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nseg * d) return;
-    float s = 0.f;
-    for (int r = 0; r < nblk; ++r) s += partial[(size_t)r * nseg * d + c];
-    if (c < d) out0[c] = s;
-    else out1[c - d] = s;
+// Block = 64 columns x 16 row slices (fixed summation order -> deterministic).
+__global__ __launch_bounds__(1024) void column_reduce_kernel(const float* __restrict__ partial,
+                                                              float* __restrict__ out0, float* __restrict__ out1,
+                                                              int nblk, int d, int nseg) {
+    __shared__ float sh[16][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int width = nseg * d;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < width) {
+        int r = slice;
+        for (; r + 16 < nblk; r += 32) {
+            s0 += partial[(size_t)r * width + c];
+            s1 += partial[(size_t)(r + 16) * width + c];
+        }
+        if (r < nblk) s0 += partial[(size_t)r * width + c];
+    }
+    sh[slice][lane] = s0 + s1;
+    __syncthreads();
+    if (slice == 0 && c < width) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += sh[k][lane];
+        if (c < d) out0[c] = s;
+        else out1[c - d] = s;
+    }
 }
 
 // ---------------------------------------------------------------------------
 // bias + activation (+ dropout)
 // ---------------------------------------------------------------------------
+// erf for the bf16 path: Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 resolution)
+// on v_rcp/v_exp; the fp32 path keeps the libm erff so fp32 parity stays at rounding level.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+    const float r = fmaf(-poly * t, e, 1.f);
+    return copysignf(r, x);
+}
+template <bool FAST>
 __device__ __forceinline__ float act_fwd(float x, int act) {
     if (act == MGX_ACT_RELU) return fmaxf(x, 0.f);
-    return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+    const float z = x * 0.70710678118654752440f;
+    return 0.5f * x * (1.f + (FAST ? erf_fast(z) : erff(z)));
 }
+template <bool FAST>
 __device__ __forceinline__ float act_grad(float x, int act) {
     if (act == MGX_ACT_RELU) return x > 0.f ? 1.f : 0.f;
-    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+    const float z = x * 0.70710678118654752440f;
+    const float cdf = 0.5f * (1.f + (FAST ? erf_fast(z) : erff(z)));
+    const float pdf = 0.3989422804014327f * (FAST ? __builtin_amdgcn_exp2f(-0.5f * x * x * 1.4426950408889634f)
+                                                  : expf(-0.5f * x * x));
     return cdf + x * pdf;
 }
 
@@ -231,7 +277,9 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const T* __restrict__
                                                             T* __restrict__ pre, T* __restrict__ h, long total, int n,
                                                             int act, float p_drop, unsigned long long seed) {
     constexpr int N = Vec<T>::N;
-    const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    constexpr bool FAST = sizeof(T) == 2;
+    const unsigned thr16 = mgx_drop_thr16(p_drop);
+    const float keep_scale = mgx_keep_scale(thr16);
     for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * N; e < total; e += (long)gridDim.x * 256 * N) {
         const int col = (int)(e % n);
         float v[N], o[N];
@@ -244,9 +292,15 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const T* __restrict__
             for (int k = 0; k < N; ++k) v[k] = to_f32(from_f32<T>(v[k]));
         }
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            o[k] = act_fwd(v[k], act);
-            if (p_drop > 0.f) o[k] = mgx_uniform(seed, (unsigned long long)(e + k)) >= p_drop ? o[k] * keep_scale : 0.f;
+        for (int k = 0; k < N; k += 2) {
+            o[k] = act_fwd<FAST>(v[k], act);
+            o[k + 1] = act_fwd<FAST>(v[k + 1], act);
+            if (p_drop > 0.f) {
+                bool k0, k1;
+                mgx_keep_pair(seed, (unsigned long long)(e + k), thr16, k0, k1);
+                o[k] = k0 ? o[k] * keep_scale : 0.f;
+                o[k + 1] = k1 ? o[k + 1] * keep_scale : 0.f;
+            }
         }
         store_vec<T, N>(h + e, o);
     }
@@ -260,7 +314,9 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
                                                             long T_rows, int n, int act, float p_drop,
                                                             unsigned long long seed) {
     constexpr int N = Vec<T>::N;
-    const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    constexpr bool FAST = sizeof(T) == 2;
+    const unsigned thr16 = mgx_drop_thr16(p_drop);
+    const float keep_scale = mgx_keep_scale(thr16);
     for (int col = threadIdx.x * N; col < n; col += 256 * N) {
         float acc[N];
 #pragma unroll
@@ -271,9 +327,15 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
             load_vec<T, N>(dh + e, g);
             load_vec<T, N>(pre + e, x);
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
-                if (p_drop > 0.f) g[k] = mgx_uniform(seed, (unsigned long long)(e + k)) >= p_drop ? g[k] * keep_scale : 0.f;
-                g[k] *= act_grad(x[k], act);
+            for (int k = 0; k < N; k += 2) {
+                if (p_drop > 0.f) {
+                    bool k0, k1;
+                    mgx_keep_pair(seed, (unsigned long long)(e + k), thr16, k0, k1);
+                    g[k] = k0 ? g[k] * keep_scale : 0.f;
+                    g[k + 1] = k1 ? g[k + 1] * keep_scale : 0.f;
+                }
+                g[k] *= act_grad<FAST>(x[k], act);
+                g[k + 1] *= act_grad<FAST>(x[k + 1], act);
             }
             store_vec<T, N>(dpre + e, g);
 #pragma unroll
@@ -344,7 +406,7 @@ int ln_bwd_launch(const void* dy, const void* dy2, const void* z, const float* m
     else LN_BWD_CASE(8);
 #undef LN_BWD_CASE
     MGX_CHECK_LAUNCH("ln_bwd");
-    hipLaunchKernelGGL(column_reduce_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, st, partial, dgamma, dbeta, nblk,
+    hipLaunchKernelGGL(column_reduce_kernel, dim3((2 * d + 63) / 64), dim3(1024), 0, st, partial, dgamma, dbeta, nblk,
                        d, 2);
     MGX_CHECK_LAUNCH("ln_bwd_reduce");
     return MGX_OK;
@@ -426,7 +488,7 @@ extern "C" int mgx_bias_act_bwd(const void* dh, const void* pre, void* dpre, flo
         hipLaunchKernelGGL((bias_act_bwd_kernel<bf16_t>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)dh,
                            (const bf16_t*)pre, (bf16_t*)dpre, partial, T, n, act, p_drop, seed);
     MGX_CHECK_LAUNCH("bias_act_bwd");
-    hipLaunchKernelGGL(column_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, dbias, dbias, nblk, n, 1);
+    hipLaunchKernelGGL(column_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial, dbias, dbias, nblk, n, 1);
     MGX_CHECK_LAUNCH("bias_act_bwd_reduce");
     return MGX_OK;
 }

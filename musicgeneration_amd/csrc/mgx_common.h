@@ -51,11 +51,25 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// Counter-based dropout hash: uniform in [0,1) from (seed, element index).
-__device__ __forceinline__ float mgx_uniform(unsigned long long seed, unsigned long long idx) {
-    unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);
+// Counter-based dropout: one 32-bit hash serves two elements (16 random bits each).
+// keep(element idx) <=> bits16(hash(seed, idx >> 1), idx & 1) >= thr16, thr16 = round(p * 65536);
+// the kept fraction is exactly 1 - thr16/65536 and kernels scale kept values by its inverse.
+__device__ __forceinline__ unsigned mgx_hash32(unsigned long long seed, unsigned long long pair_idx) {
+    unsigned x = (unsigned)pair_idx ^ (unsigned)seed;
+    x += (unsigned)(pair_idx >> 32) * 0x9E3779B9u + (unsigned)(seed >> 32);
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned mgx_drop_thr16(float p) { return (unsigned)(p * 65536.0f + 0.5f); }
+__device__ __forceinline__ float mgx_keep_scale(unsigned thr16) { return 65536.0f / (float)(65536u - thr16); }
+// element idx must be even for the _pair form; returns keep flags for idx and idx+1
+__device__ __forceinline__ void mgx_keep_pair(unsigned long long seed, unsigned long long idx, unsigned thr16,
+                                              bool& k0, bool& k1) {
+    const unsigned h = mgx_hash32(seed, idx >> 1);
+    k0 = (h & 0xFFFFu) >= thr16;
+    k1 = (h >> 16) >= thr16;
 }

@@ -108,6 +108,31 @@ def test_alibi_attention_bf16_asymmetric_exact():
     assert gu.rel_err(out.float(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("dh", [64, 128])
+def test_alibi_attention_bf16_rescale_branch(dh):
+    """Forces the deferred-rescale branch of the flash kernel (guide rule 26): one key per row block
+    is spiked so the running max jumps by far more than the threshold at a chosen tile, after
+    tiles that were accumulated against the old max; compared on the FULL tensor."""
+    ops = _ops()
+    B, S, H = 1, 448, 2
+    g = torch.Generator().manual_seed(11)
+    q = 0.3 * torch.randn(B, S, H, dh, generator=g)
+    k = 0.3 * torch.randn(B, S, H, dh, generator=g)
+    v = torch.randn(B, S, H, dh, generator=g)
+    for j in (70, 200, 330):                      # keys in tiles 1, 3, 5
+        k[0, j] = 6.0 * q[0, j + 40] / q[0, j + 40].norm(dim=-1, keepdim=True)   # aligned with a later query
+    qkv = torch.cat([q.reshape(B, S, -1), k.reshape(B, S, -1), v.reshape(B, S, -1)], -1).bfloat16()
+    dout = torch.randn(B, S, H * dh, generator=g).bfloat16()
+    slopes = torch.tensor(O.alibi_slopes(H), dtype=torch.float32)
+    ref_in = qkv.float().requires_grad_(True)
+    ref = _ref_attn(ref_in, H)
+    ref.backward(dout.float())
+    out, lse = ops.alibi_attn_fwd(qkv.cuda(), slopes.cuda(), H)
+    assert gu.rel_err(out.float(), ref) < BF16_TOL
+    dqkv = ops.alibi_attn_bwd(dout.cuda(), qkv.cuda(), out, lse, slopes.cuda(), H)
+    assert gu.rel_err(dqkv.float(), ref_in.grad) < BF16_TOL
+
+
 @pytest.mark.parametrize("B,S,H,dh,M", [(2, 40, 8, 8, 64), (1, 64, 4, 16, 64), (2, 150, 2, 64, 160)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_relative_attention(B, S, H, dh, M, dtype):
