@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmgx.so")
+LIB_PATH = os.environ.get("MGX_LIB") or os.path.join(_HERE, "libmgx.so")    # MGX_LIB: A/B builds during tuning
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

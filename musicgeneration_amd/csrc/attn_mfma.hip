@@ -24,6 +24,18 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float RESCALE_LOG2 = 8.0f;
+#ifndef MGX_DQ_OCC
+#define MGX_DQ_OCC 2             // waves per SIMD the dQ kernel is compiled for
+#endif
+#ifndef MGX_DKV_OCC
+#define MGX_DKV_OCC (DH == 128 ? NW / 4 : 2)
+#endif
+#ifndef MGX_DKV_NW
+#define MGX_DKV_NW 4             // dK/dV kernel: 4 waves, one per SIMD, 512 registers each at dh=128
+#endif
+#ifndef MGX_ATTN_NW
+#define MGX_ATTN_NW 8            // waves (x 32 rows) per workgroup
+#endif
 
 template <int DH>
 struct Img {
@@ -70,30 +82,30 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& s, int base) {
     return r;
 }
 
-// Stage one [64 x DH] bf16 tile: global rows r0.. (row stride rs elements) -> registers.
-template <int DH>
+// Stage one [64 x DH] bf16 tile: global rows r0.. (row stride rs elements) -> registers -> LDS image.
+template <int DH, int NT>
 struct TileRegs {
-    bf16x8 v[DH / 32];
+    bf16x8 v[8 * DH / NT];
 };
 
 // Rows past the end are clamped to row S-1 instead of zero-filled: every consumer multiplies them
 // by an exactly-zero probability (causal mask / -inf row statistic), so real finite data is as good
 // as zeros and the load needs no branch.  Offsets are 32-bit (launchers check S*row_bytes < 2^31).
-template <int DH>
-__device__ __forceinline__ void tile_load(TileRegs<DH>& t, const bf16_t* src, unsigned rs, int r0, int S, int tid) {
+template <int DH, int NT>
+__device__ __forceinline__ void tile_load(TileRegs<DH, NT>& t, const bf16_t* src, unsigned rs, int r0, int S, int tid) {
 #pragma unroll
-    for (int n = 0; n < DH / 32; ++n) {
-        const int e = tid + 256 * n;
+    for (int n = 0; n < 8 * DH / NT; ++n) {
+        const int e = tid + NT * n;
         const int row = e / Img<DH>::CPR, ch = e % Img<DH>::CPR;
         const unsigned g = (unsigned)min(r0 + row, S - 1);
         t.v[n] = *reinterpret_cast<const bf16x8*>(src + (g * rs + (unsigned)(ch * 8)));
     }
 }
-template <int DH>
-__device__ __forceinline__ void tile_store(const TileRegs<DH>& t, char* img, int tid) {
+template <int DH, int NT>
+__device__ __forceinline__ void tile_store(const TileRegs<DH, NT>& t, char* img, int tid) {
 #pragma unroll
-    for (int n = 0; n < DH / 32; ++n) {
-        const int e = tid + 256 * n;
+    for (int n = 0; n < 8 * DH / NT; ++n) {
+        const int e = tid + NT * n;
         const int row = e / Img<DH>::CPR, ch = e % Img<DH>::CPR;
         *reinterpret_cast<bf16x8*>(img + Img<DH>::off(row, ch)) = t.v[n];
     }
@@ -127,19 +139,21 @@ struct LaneAddr {
 // ===========================================================================
 // forward
 // ===========================================================================
-template <int DH>
-__global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv,
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv,
                                                                 const float* __restrict__ slopes,
                                                                 bf16_t* __restrict__ out, float* __restrict__ lse,
                                                                 int S, int H, float c /* scale*log2e */) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * Img<DH>::TILE_BYTES];
-    char* Ks = smem;
-    char* Vs = smem + Img<DH>::TILE_BYTES;
+    constexpr int NT = 64 * NW, QB = 32 * NW, TB = Img<DH>::TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[4 * TB];      // 2 buffers x (K image, V image)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, h5 = lane >> 5;
-    const int qb = gridDim.x - 1 - blockIdx.x;          // heaviest (latest) query blocks first
-    const int q0 = qb * 128, qw0 = q0 + 32 * w;
-    const int b = blockIdx.z, h = blockIdx.y;
+    // grid = (H, B, q-blocks): the q-block index is the slowest dispatch dimension, so ALL the heavy
+    // (late, long-context) blocks start first and the tail of the launch is made of the lightest ones;
+    // blocks of one (b,h) are 8k apart in dispatch order, i.e. on one XCD (shared K/V in its L2).
+    const int qb = gridDim.z - 1 - blockIdx.z;
+    const int q0 = qb * QB, qw0 = q0 + 32 * w;
+    const int b = blockIdx.y, h = blockIdx.x;
     const unsigned rs = 3u * H * DH;
     const bf16_t* base = qkv + (long)b * S * rs + (long)h * DH;
     const bf16_t* kp = base + (long)H * DH;
@@ -163,20 +177,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const bf16_t* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
 
-    const int kmax = min(q0 + 128, S);                   // keys [0, kmax)
+    const int kmax = min(q0 + QB, S);                    // keys [0, kmax)
     const int ntiles = (kmax + 63) / 64;
-    TileRegs<DH> kr, vr;
-    tile_load<DH>(kr, kp, rs, 0, S, tid);
-    tile_load<DH>(vr, vp, rs, 0, S, tid);
+    // Double-buffered staging, one barrier per tile: while tile t is consumed from buffer t&1,
+    // tile t+1 (already in registers) is written to the other buffer and tile t+2 is fetched.
+    TileRegs<DH, NT> kr, vr;
+    tile_load<DH, NT>(kr, kp, rs, 0, S, tid);
+    tile_load<DH, NT>(vr, vp, rs, 0, S, tid);
+    tile_store<DH, NT>(kr, smem, tid);
+    tile_store<DH, NT>(vr, smem + TB, tid);
+    if (ntiles > 1) {
+        tile_load<DH, NT>(kr, kp, rs, 64, S, tid);
+        tile_load<DH, NT>(vr, vp, rs, 64, S, tid);
+    }
+    __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * 64;
-        __syncthreads();
-        tile_store<DH>(kr, Ks, tid);
-        tile_store<DH>(vr, Vs, tid);
-        __syncthreads();
+        const char* Ks = smem + (t & 1) * 2 * TB;
+        const char* Vs = Ks + TB;
         if (t + 1 < ntiles) {
-            tile_load<DH>(kr, kp, rs, j0 + 64, S, tid);
-            tile_load<DH>(vr, vp, rs, j0 + 64, S, tid);
+            char* Kn = smem + ((t + 1) & 1) * 2 * TB;
+            tile_store<DH, NT>(kr, Kn, tid);
+            tile_store<DH, NT>(vr, Kn + TB, tid);
+        }
+        if (t + 2 < ntiles) {
+            tile_load<DH, NT>(kr, kp, rs, j0 + 128, S, tid);
+            tile_load<DH, NT>(vr, vp, rs, j0 + 128, S, tid);
         }
         if (j0 <= qw0 + 31) {                             // wave-uniform
             f32x16 s[2];
@@ -242,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const bf16_t* __r
                     }
                 }
         }
+        __syncthreads();
     }
     const float lt = half_swap_sum(l);
     const float inv = 1.f / lt;
@@ -293,19 +320,18 @@ __global__ __launch_bounds__(256) void attn_delta_mfma_kernel(const bf16_t* __re
 
 // dQ: query on the lane (as the forward).  Per 32-key block:
 //   S^T = K.Q^T (+bias)   dP^T = V.dO^T (-delta)   dS^T = P^T*(dP^T)*scale   dQ^T += K^T.dS^T
-template <int DH>
-__global__ __launch_bounds__(256, (DH == 128 ? 1 : 2)) void attn_bwd_dq_mfma_kernel(
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW, MGX_DQ_OCC) void attn_bwd_dq_mfma_kernel(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
     const float* __restrict__ delta, const float* __restrict__ slopes, bf16_t* __restrict__ dqkv, int S, int H,
     float c, float scale) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * Img<DH>::TILE_BYTES];
-    char* Ks = smem;
-    char* Vs = smem + Img<DH>::TILE_BYTES;
+    constexpr int NT = 64 * NW, QB = 32 * NW, TB = Img<DH>::TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[4 * TB];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, h5 = lane >> 5;
-    const int qb = gridDim.x - 1 - blockIdx.x;
-    const int q0 = qb * 128, qw0 = q0 + 32 * w;
-    const int b = blockIdx.z, h = blockIdx.y;
+    const int qb = gridDim.z - 1 - blockIdx.z;
+    const int q0 = qb * QB, qw0 = q0 + 32 * w;
+    const int b = blockIdx.y, h = blockIdx.x;
     const unsigned rs = 3u * H * DH;
     const bf16_t* base = qkv + (long)b * S * rs + (long)h * DH;
     const bf16_t* kp = base + (long)H * DH;
@@ -332,20 +358,30 @@ __global__ __launch_bounds__(256, (DH == 128 ? 1 : 2)) void attn_bwd_dq_mfma_ker
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
 
-    const int kmax = min(q0 + 128, S);
+    const int kmax = min(q0 + QB, S);
     const int ntiles = (kmax + 63) / 64;
-    TileRegs<DH> kr, vr;
-    tile_load<DH>(kr, kp, rs, 0, S, tid);
-    tile_load<DH>(vr, vp, rs, 0, S, tid);
+    TileRegs<DH, NT> kr, vr;
+    tile_load<DH, NT>(kr, kp, rs, 0, S, tid);
+    tile_load<DH, NT>(vr, vp, rs, 0, S, tid);
+    tile_store<DH, NT>(kr, smem, tid);
+    tile_store<DH, NT>(vr, smem + TB, tid);
+    if (ntiles > 1) {
+        tile_load<DH, NT>(kr, kp, rs, 64, S, tid);
+        tile_load<DH, NT>(vr, vp, rs, 64, S, tid);
+    }
+    __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * 64;
-        __syncthreads();
-        tile_store<DH>(kr, Ks, tid);
-        tile_store<DH>(vr, Vs, tid);
-        __syncthreads();
+        const char* Ks = smem + (t & 1) * 2 * TB;
+        const char* Vs = Ks + TB;
         if (t + 1 < ntiles) {
-            tile_load<DH>(kr, kp, rs, j0 + 64, S, tid);
-            tile_load<DH>(vr, vp, rs, j0 + 64, S, tid);
+            char* Kn = smem + ((t + 1) & 1) * 2 * TB;
+            tile_store<DH, NT>(kr, Kn, tid);
+            tile_store<DH, NT>(vr, Kn + TB, tid);
+        }
+        if (t + 2 < ntiles) {
+            tile_load<DH, NT>(kr, kp, rs, j0 + 128, S, tid);
+            tile_load<DH, NT>(vr, vp, rs, j0 + 128, S, tid);
         }
         if (j0 <= qw0 + 31) {
             const float lb = sb * (float)(j0 + 4 * h5 - qi);
@@ -382,6 +418,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 1 : 2)) void attn_bwd_dq_mfma_ker
                 }
             }
         }
+        __syncthreads();
     }
     if (qok) {
         bf16_t* op = dqkv + ((long)b * S + qi) * rs + (long)h * DH;
@@ -400,20 +437,19 @@ __global__ __launch_bounds__(256, (DH == 128 ? 1 : 2)) void attn_bwd_dq_mfma_ker
 // dK, dV: key on the lane.  Per 32-query block of a 64-query tile:
 //   S = Q.K^T (+bias-lse)  dP = dO.V^T (-delta)  P = exp2, dS = P*dP*scale
 //   dV^T += dO^T.P         dK^T += Q^T.dS        (P, dS straight from the accumulators)
-template <int DH>
-__global__ __launch_bounds__(256, (DH == 128 ? 1 : 2)) void attn_bwd_dkv_mfma_kernel(
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW, MGX_DKV_OCC) void attn_bwd_dkv_mfma_kernel(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
     const float* __restrict__ delta, const float* __restrict__ slopes, bf16_t* __restrict__ dqkv, int S, int H,
     float c, float scale) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * Img<DH>::TILE_BYTES + 2 * 64 * sizeof(float)];
-    char* Qs = smem;
-    char* Gs = smem + Img<DH>::TILE_BYTES;
-    float* Ls = reinterpret_cast<float*>(smem + 2 * Img<DH>::TILE_BYTES);
-    float* Dn = Ls + 64;
+    constexpr int NT = 64 * NW, KB = 32 * NW, TB = Img<DH>::TILE_BYTES;
+    // 2 buffers x (Q image, dO image), then 2 x (row stats L[64], -delta[64])
+    __shared__ __attribute__((aligned(16))) char smem[4 * TB + 4 * 64 * sizeof(float)];
+    float* stats = reinterpret_cast<float*>(smem + 4 * TB);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, h5 = lane >> 5;
-    const int jb0 = blockIdx.x * 128, jw0 = jb0 + 32 * w;
-    const int b = blockIdx.z, h = blockIdx.y;
+    const int jb0 = blockIdx.z * KB, jw0 = jb0 + 32 * w;      // early key blocks (most queries) first
+    const int b = blockIdx.y, h = blockIdx.x;
     const unsigned rs = 3u * H * DH;
     const bf16_t* base = qkv + (long)b * S * rs + (long)h * DH;
     const bf16_t* kp = base + (long)H * DH;
@@ -443,33 +479,38 @@ __global__ __launch_bounds__(256, (DH == 128 ? 1 : 2)) void attn_bwd_dkv_mfma_ke
 
     const int t0 = jb0 / 64;
     const int ntiles = (S + 63) / 64;
-    TileRegs<DH> qr, gr;
+    TileRegs<DH, NT> qr, gr;
     float r_lse = 0.f, r_delta = 0.f;
-    tile_load<DH>(qr, base, rs, t0 * 64, S, tid);
-    tile_load<DH>(gr, gp, (unsigned)(H * DH), t0 * 64, S, tid);
-    if (tid < 64 && t0 * 64 + tid < S) {
-        r_lse = lse_bh[t0 * 64 + tid];
-        r_delta = delta_bh[t0 * 64 + tid];
-    }
-    for (int t = t0; t < ntiles; ++t) {
-        const int i0 = t * 64;
-        __syncthreads();
-        tile_store<DH>(qr, Qs, tid);
-        tile_store<DH>(gr, Gs, tid);
+    auto load_tile = [&](int i0) {
+        tile_load<DH, NT>(qr, base, rs, i0, S, tid);
+        tile_load<DH, NT>(gr, gp, (unsigned)(H * DH), i0, S, tid);
+        if (tid < 64 && i0 + tid < S) {
+            r_lse = lse_bh[i0 + tid];
+            r_delta = delta_bh[i0 + tid];
+        }
+    };
+    auto store_tile = [&](int i0, int buf) {
+        tile_store<DH, NT>(qr, smem + buf * 2 * TB, tid);
+        tile_store<DH, NT>(gr, smem + buf * 2 * TB + TB, tid);
         if (tid < 64) {
             const bool ok = i0 + tid < S;
-            Ls[tid] = ok ? -(sb * (float)tid + r_lse * LOG2E * inv_c) : -INFINITY;
-            Dn[tid] = ok ? -r_delta : 0.f;
+            stats[buf * 128 + tid] = ok ? -(sb * (float)tid + r_lse * LOG2E * inv_c) : -INFINITY;
+            stats[buf * 128 + 64 + tid] = ok ? -r_delta : 0.f;
         }
-        __syncthreads();
-        if (t + 1 < ntiles) {
-            tile_load<DH>(qr, base, rs, i0 + 64, S, tid);
-            tile_load<DH>(gr, gp, (unsigned)(H * DH), i0 + 64, S, tid);
-            if (tid < 64 && i0 + 64 + tid < S) {
-                r_lse = lse_bh[i0 + 64 + tid];
-                r_delta = delta_bh[i0 + 64 + tid];
-            }
-        }
+    };
+    load_tile(t0 * 64);
+    store_tile(t0 * 64, 0);
+    if (t0 + 1 < ntiles) load_tile(t0 * 64 + 64);
+    __syncthreads();
+    for (int t = t0; t < ntiles; ++t) {
+        const int i0 = t * 64;
+        const int buf = (t - t0) & 1;
+        const char* Qs = smem + buf * 2 * TB;
+        const char* Gs = Qs + TB;
+        const float* Ls = stats + buf * 128;
+        const float* Dn = Ls + 64;
+        if (t + 1 < ntiles) store_tile(i0 + 64, buf ^ 1);
+        if (t + 2 < ntiles) load_tile(i0 + 128);
         if (i0 + 63 >= jw0) {                                      // wave-uniform
             const float cj = sb * (float)(j - i0);
             const bool diag = i0 < jw0 + 31;
@@ -514,6 +555,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 1 : 2)) void attn_bwd_dkv_mfma_ke
                 }
             }
         }
+        __syncthreads();
     }
     if (jok) {
         bf16_t* op = dqkv + ((long)b * S + j) * rs + (long)h * DH;
@@ -533,7 +575,7 @@ __global__ __launch_bounds__(256, (DH == 128 ? 1 : 2)) void attn_bwd_dkv_mfma_ke
     }
 }
 
-template <int DH>
+template <int DH, int NW>
 int launch_bwd_mfma(const void* dout, const void* qkv, const void* out, const float* lse, const float* slopes,
                     void* dqkv, float* delta, int B, int S, int H, hipStream_t st) {
     const float scale = 1.0f / sqrtf((float)DH);
@@ -542,11 +584,13 @@ int launch_bwd_mfma(const void* dout, const void* qkv, const void* out, const fl
     hipLaunchKernelGGL((attn_delta_mfma_kernel<DH>), dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st,
                        (const bf16_t*)dout, (const bf16_t*)out, delta, n_chunks, S, H);
     MGX_CHECK_LAUNCH("attn_delta_mfma");
-    dim3 grid((S + 127) / 128, H, B);
-    hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<DH>), grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)qkv,
-                       lse, delta, slopes, (bf16_t*)dqkv, S, H, c, scale);
+    constexpr int NWK = MGX_DKV_NW;
+    dim3 gridk(H, B, (S + 32 * NWK - 1) / (32 * NWK));
+    hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<DH, NWK>), gridk, dim3(64 * NWK), 0, st, (const bf16_t*)dout,
+                       (const bf16_t*)qkv, lse, delta, slopes, (bf16_t*)dqkv, S, H, c, scale);
     MGX_CHECK_LAUNCH("attn_bwd_dkv_mfma");
-    hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DH>), grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)qkv,
+    dim3 grid(H, B, (S + 32 * NW - 1) / (32 * NW));
+    hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DH, NW>), grid, dim3(64 * NW), 0, st, (const bf16_t*)dout, (const bf16_t*)qkv,
                        lse, delta, slopes, (bf16_t*)dqkv, S, H, c, scale);
     MGX_CHECK_LAUNCH("attn_bwd_dq_mfma");
     return MGX_OK;
@@ -565,12 +609,13 @@ int mgx_attn_fwd_mfma(int mode, const void* qkv, const float* slopes, const void
     (void)max_seq;
     MGX_REQUIRE(mode == 0, MGX_EUNSUPPORTED, "mgx_attn_fwd_mfma: mode %d", mode);
     const float c = LOG2E / sqrtf((float)dh);
-    dim3 grid((S + 127) / 128, H, B);
+    constexpr int NW = MGX_ATTN_NW;
+    dim3 grid(H, B, (S + 32 * NW - 1) / (32 * NW));
     if (dh == 64)
-        hipLaunchKernelGGL((attn_fwd_mfma_kernel<64>), grid, dim3(256), 0, st, (const bf16_t*)qkv, slopes,
+        hipLaunchKernelGGL((attn_fwd_mfma_kernel<64, NW>), grid, dim3(64 * NW), 0, st, (const bf16_t*)qkv, slopes,
                            (bf16_t*)out, lse, S, H, c);
     else
-        hipLaunchKernelGGL((attn_fwd_mfma_kernel<128>), grid, dim3(256), 0, st, (const bf16_t*)qkv, slopes,
+        hipLaunchKernelGGL((attn_fwd_mfma_kernel<128, NW>), grid, dim3(64 * NW), 0, st, (const bf16_t*)qkv, slopes,
                            (bf16_t*)out, lse, S, H, c);
     MGX_CHECK_LAUNCH("attn_fwd_mfma");
     return MGX_OK;
@@ -583,6 +628,6 @@ int mgx_attn_bwd_mfma(int mode, const void* dout, const void* qkv, const void* o
     (void)dE;
     (void)max_seq;
     MGX_REQUIRE(mode == 0, MGX_EUNSUPPORTED, "mgx_attn_bwd_mfma: mode %d", mode);
-    if (dh == 64) return launch_bwd_mfma<64>(dout, qkv, out, lse, slopes, dqkv, delta, B, S, H, st);
-    return launch_bwd_mfma<128>(dout, qkv, out, lse, slopes, dqkv, delta, B, S, H, st);
+    if (dh == 64) return launch_bwd_mfma<64, MGX_ATTN_NW>(dout, qkv, out, lse, slopes, dqkv, delta, B, S, H, st);
+    return launch_bwd_mfma<128, MGX_ATTN_NW>(dout, qkv, out, lse, slopes, dqkv, delta, B, S, H, st);
 }
