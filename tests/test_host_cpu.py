@@ -1,0 +1,146 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/mgx.h
+declares, host-side helpers behave like the reference's, product path refuses to run
+without a GPU, data-parallel bucketing averages gradients (gloo, world_size 2)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from musicgeneration_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mgx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mgx_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(_lib.lib, name), f"{name} declared in mgx.h but not exported by libmgx.so"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert _lib.lib.mgx_version() >= 100
+
+
+def test_product_path_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "musicgeneration_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("oracle/", ""), f"{f} mentions the oracle"
+
+
+def test_no_cpu_fallback():
+    from musicgeneration_amd import ops
+    from musicgeneration_amd.model_baseline.alibi_unified import AlibiTransformer
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.alibi_attn_fwd(torch.zeros(1, 4, 24), torch.ones(1), 1)
+    m = AlibiTransformer(vocab=20, embed_dim=16, n_layers=1, n_heads=2, max_sequence=8, proj_forward=32)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 4, dtype=torch.long))
+
+
+def test_slopes_and_mask_helpers_match_reference():
+    from musicgeneration_amd.model_baseline.alibi_unified import construct_alibi, get_slopes
+    from musicgeneration_amd.base_layers import generate_square_subsequent_mask
+    z = gu.load("alibi_basics")
+    for n in range(1, 33):
+        assert np.array_equal(np.array(get_slopes(n), dtype=np.float64), z[f"slopes_{n}"]), n
+    assert torch.equal(construct_alibi(16, 8), torch.from_numpy(z["mask_h8_s16"]))
+    assert torch.equal(construct_alibi(12, 6), torch.from_numpy(z["mask_h6_s12"]))
+    assert torch.equal(generate_square_subsequent_mask(9, "cpu"), torch.from_numpy(z["causal_9"]))
+
+
+def test_constructor_api_and_state_dict_keys():
+    from musicgeneration_amd.misc import EasyDict
+    from musicgeneration_amd.model_baseline import alibi_unified, alibi_separated
+    from musicgeneration_amd.old_models.relative_transformer import RelativeTransformer
+    a = EasyDict(vocab=618, embed_dim=64, n_layers=2, n_heads=8, max_sequence=64, proj_forward=128, dropout=0.0,
+                 activation="gelu", pad_index=1)
+    m, c = alibi_unified.build_model_and_criterion(a)          # extra key pad_index swallowed by **kwargs
+    ref = {k[3:] for k in gu.load("unified_tiny").files if k.startswith("sd.")}
+    assert set(m.state_dict()) == ref and c.ignore_index == 1 and len(c.state_dict()) == 0
+    with pytest.raises(AttributeError):
+        a.nope
+    s = EasyDict(vocab_note=92, vocab_velocity=130, vocab_duration=203, embed_note=16, embed_velocity=16,
+                 embed_duration=32, n_layers=2, n_heads=8, max_sequence=64, proj_forward=128, dropout=0.0,
+                 loss_weights={"loss_notes": 1, "loss_velocity": 1, "loss_duration": 1})
+    ms, cs = alibi_separated.build_model_and_criterion(s)
+    ref = {k[3:] for k in gu.load("separated_tiny").files if k.startswith("sd.")}
+    assert set(ms.state_dict()) == ref
+    assert sorted(cs.state_dict()) == ["weight_n", "weight_v"]
+    r = RelativeTransformer(618, 64, 2, 8, 64, 128)
+    ref = {k[3:] for k in gu.load("relative_tiny").files if k.startswith("sd.")}
+    assert set(r.state_dict()) == ref
+    assert "mask" in r.reference_state_dict() and "mask" in m.reference_state_dict()
+
+
+def test_checkpoint_helpers(tmp_path):
+    from musicgeneration_amd import train_utils as tu
+    for s in (30, 4, 100, 7):
+        tu.save_checkpoint({"steps": s}, s, str(tmp_path))
+    names = [os.path.basename(p) for p in tu.get_checkpoints(str(tmp_path))]
+    assert names == ["4.tar", "7.tar", "30.tar", "100.tar"]          # integer order, newest last
+    tu.remove_extra_checkpoints(str(tmp_path), keep=2)
+    assert [os.path.basename(p) for p in tu.get_checkpoints(str(tmp_path))] == ["30.tar", "100.tar"]
+    assert tu.recursive_cast({"a": [1, (2, 3)], "b": 4}, lambda v: v * 2) == {"a": [2, [4, 6]], "b": 8}
+    assert tu.log_scalars({"loss": 1.0}, 3, "train") == {"train/loss": 1.0}
+
+
+def test_logger_and_metrics_duck_type():
+    from musicgeneration_amd import train_utils as tu
+    from musicgeneration_amd.model_baseline.alibi_unified import Metrics
+    lg = tu.Logger.remote(None, Metrics())
+    y = torch.tensor([[1, 2, 3, 4], [1, 1, 1, 1]])
+    lg.step.remote(torch.tensor([[1, 2, 0, 0], [1, 1, 1, 1]]), y, {"loss": torch.tensor(2.0)})
+    lg.step.remote(y.clone(), y, {"loss": torch.tensor(4.0)})
+    lg.log.remote(16, 2)
+    steps, rec = lg.history[0]
+    assert steps == 16 and rec["train/loss"] == 3.0
+    assert abs(float(rec["train/accuracy"]) - (0.5 + 1 + 1 + 1) / 4) < 1e-6
+
+
+_DP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MGX_ROOT"])
+from musicgeneration_amd.data_parallel import GradientBucketer
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(100 + rank)                       # different init per rank: the bucketer must broadcast rank 0's
+model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 4))
+ddp = GradientBucketer(model, bucket_mb=0.002)      # tiny buckets -> several of them
+assert len(ddp.buckets) > 1
+g = torch.Generator().manual_seed(7)
+X = torch.randn(8, 16, generator=g); Y = torch.randn(8, 4, generator=g)
+xs, ys = X[rank::world], Y[rank::world]
+for it in range(2):
+    model.zero_grad()
+    ((model(xs) - ys) ** 2).mean().backward()
+    ddp.finish()
+# single-process reference on the whole batch with rank 0's weights
+torch.manual_seed(100)
+ref = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 4))
+((ref(X) - Y) ** 2).mean().backward()
+for p, q in zip(model.parameters(), ref.parameters()):
+    assert torch.allclose(p.detach(), q.detach()), "weights not broadcast"
+    assert torch.allclose(p.grad, q.grad, atol=1e-6), "averaged gradient differs from the full-batch gradient"
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_gradient_bucketer_gloo_world2(tmp_path):
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER)
+    env = dict(os.environ, MGX_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("ok") == 2
