@@ -149,6 +149,24 @@ int mgx_adamw(float* param, const void* grad, float* exp_avg, float* exp_avg_sq,
               long n, float lr, float beta1, float beta2, float eps, float weight_decay,
               int step, float grad_scale, int grad_dtype, void* stream);
 
+/* ---- bf16 MFMA GEMMs for the projections ----------------------------------------------------
+ * Replace Conv1d.forward (base_layers.py:54-57) and nn.Linear (alibi_unified.py:90,92) and their
+ * autograd GEMMs.  Tile 256x256x64, fp32 accumulate.
+ * NT: C[M,N] = A[M,K] . Bt[N,K]^T (+ bias[N] fp32) (+ res[M,N] bf16); all bf16, K % 64 == 0,
+ *     lda/ldb/ldc multiples of 8.  act = -1: nothing more.  act = MGX_ACT_*: C receives the
+ *     pre-activation and C2[M,N] = dropout(act(C)) (dropout keyed by (seed, m*N+n), the same mask
+ *     mgx_bias_act_bwd regenerates).
+ */
+int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2, const float* bias, const void* res,
+                     int M, int N, int K, int lda, int ldb, int ldc, int act, float p_drop,
+                     unsigned long long seed, void* stream);
+/* TN (weight gradients): C[M,N] = A[K,M]^T . B[K,N], bf16 inputs, split over K into fp32 slabs in
+ * `workspace` (mgx_gemm_tn_workspace_floats() floats) and reduced in a fixed order (deterministic);
+ * C is fp32 or bf16 (out_dtype).  M, N, lda, ldb multiples of 8. */
+long mgx_gemm_tn_workspace_floats(int M, int N, int K, int* splits_out);
+int mgx_gemm_tn_bf16(const void* A, const void* B, void* C, float* workspace, int M, int N, int K,
+                     int lda, int ldb, int out_dtype, void* stream);
+
 /* Test hook (no reference counterpart): route attention through the generic
  * kernels (on != 0) or restore the MFMA dispatch (on == 0). */
 void mgx_debug_force_generic_attention(int on);

@@ -36,6 +36,9 @@ PROTOTYPES = {
     "mgx_decode_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mgx_kv_append": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mgx_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _i, _vp]),
+    "mgx_gemm_nt_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _vp]),
+    "mgx_gemm_tn_workspace_floats": (_l, [_i, _i, _i, _vp]),
+    "mgx_gemm_tn_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mgx_debug_force_generic_attention": (None, [_i]),
 }
 

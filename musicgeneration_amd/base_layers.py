@@ -62,8 +62,78 @@ class ShadowCache:
             self._c[key] = ent
         return ent[1] if shape is None else ent[1].view(shape)
 
+    def get_t(self, p: torch.Tensor, dtype, shape):
+        """Transposed contiguous compute-dtype copy of the 2-D view `shape` of p (cached like get)."""
+        key = (id(p), dtype, "t")
+        ent = self._c.get(key)
+        if ent is None or ent[0] != p._version or ent[1].device != p.device:
+            ent = (p._version, p.detach().view(shape).t().to(dtype).contiguous())
+            self._c[key] = ent
+        return ent[1]
+
     def clear(self):
         self._c.clear()
+
+
+class BlockWeights:
+    """Compute-dtype views of one decoder block's parameters, in every orientation the GEMMs want.
+
+    Conv1d weights are [in, out] (x @ w), nn.Linear weights [out, in].  The hand-written NT GEMM
+    takes its second operand as [N, K] (K contiguous), so each weight is served both ways; the
+    copies are made once per optimizer step (ShadowCache keys on the parameter version).
+    """
+
+    def __init__(self, cache: ShadowCache, masters, d: int, dtype):
+        (self.m_wqkv, self.m_bqkv, self.m_wp, self.m_bp, self.m_w1, self.m_b1, self.m_w2, self.m_b2,
+         self.m_g1, self.m_be1, self.m_g2, self.m_be2) = masters
+        self.masters = masters
+        self.dtype = dtype
+        self._c, self._d = cache, d
+
+    # [K, N] orientation for x @ W, [N, K] for the NT kernel
+    @property
+    def wqkv(self):            # [d, 3d]
+        return self._c.get(self.m_wqkv, self.dtype, (self._d, 3 * self._d))
+
+    @property
+    def wqkv_t(self):          # [3d, d]
+        return self._c.get_t(self.m_wqkv, self.dtype, (self._d, 3 * self._d))
+
+    @property
+    def wp(self):              # [d, d]
+        return self._c.get(self.m_wp, self.dtype, (self._d, self._d))
+
+    @property
+    def wp_t(self):
+        return self._c.get_t(self.m_wp, self.dtype, (self._d, self._d))
+
+    @property
+    def w1(self):              # [ff, d]
+        return self._c.get(self.m_w1, self.dtype)
+
+    @property
+    def w1_t(self):            # [d, ff]
+        return self._c.get_t(self.m_w1, self.dtype, tuple(self.m_w1.shape))
+
+    @property
+    def w2(self):              # [d, ff]
+        return self._c.get(self.m_w2, self.dtype)
+
+    @property
+    def w2_t(self):            # [ff, d]
+        return self._c.get_t(self.m_w2, self.dtype, tuple(self.m_w2.shape))
+
+    @property
+    def bqkv(self):
+        return self._c.get(self.m_bqkv, self.dtype)
+
+    @property
+    def bp(self):
+        return self._c.get(self.m_bp, self.dtype)
+
+    @property
+    def b2(self):
+        return self._c.get(self.m_b2, self.dtype)
 
 
 class Norm(nn.Module):

@@ -56,7 +56,8 @@ class KVCacheDecoder:
             raise ValueError("prefill (more than 4 rows) must start at position 0")
         T = B * R
         for layer, (kc, vc) in zip(m.decoder_layers, self.caches):
-            wqkv, bqkv, wp, bp, w1, w2, b2 = layer.shadows(dt)
+            W = layer.weights(dt)
+            wqkv, bqkv, wp, bp, w1, w2, b2 = W.wqkv, W.bqkv, W.wp, W.bp, W.w1, W.w2, W.b2
             x2 = h.reshape(T, d)
             qkv = torch.addmm(bqkv, x2, wqkv).view(B, R, 3 * d)
             ops.kv_append(qkv, kc, vc, pos0)

@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..base_layers import Attention, Conv1d, Norm, ShadowCache, active_dtype, resolve_dtype, \
+from ..base_layers import Attention, BlockWeights, Conv1d, Norm, ShadowCache, active_dtype, resolve_dtype, \
     generate_square_subsequent_mask
 from ..metrics import SamplewiseAccuracy
 
@@ -109,15 +109,12 @@ class DecoderBlock(nn.Module):
                 self.linear2.weight, self.linear2.bias, self.norm1.weight, self.norm1.bias,
                 self.norm2.weight, self.norm2.bias)
 
-    def shadows(self, dtype):
-        a, s, d = self.attn, self._shadow, self.n_state
-        return (s.get(a.c_attn.w, dtype, (d, 3 * d)), s.get(a.c_attn.b, dtype), s.get(a.c_proj.w, dtype, (d, d)),
-                s.get(a.c_proj.b, dtype), s.get(self.linear1.weight, dtype), s.get(self.linear2.weight, dtype),
-                s.get(self.linear2.bias, dtype))
+    def weights(self, dtype):
+        return BlockWeights(self._shadow, self.masters(), self.n_state, dtype)
 
     def forward(self, x, mask=None):
         return ops.fused_decoder_block(x, self.heads, self.activation, self.drop.p, self.norm1.eps, self.training,
-                                       self.attn.slopes, None, None, self.masters(), self.shadows(x.dtype))
+                                       self.attn.slopes, None, None, self.weights(x.dtype))
 
 
 def _activation_name(activation):

@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..base_layers import Attention, Conv1d, Norm, ShadowCache, active_dtype, resolve_dtype, \
+from ..base_layers import Attention, BlockWeights, Conv1d, Norm, ShadowCache, active_dtype, resolve_dtype, \
     generate_square_subsequent_mask
 from ..model_baseline.alibi_unified import _activation_name
 
@@ -66,15 +66,13 @@ class DecoderBlock(nn.Module):
         self._shadow = ShadowCache()
 
     def forward(self, x, mask=None):
-        a, s, d, dt = self.attn, self._shadow, self.n_state, x.dtype
+        a, dt = self.attn, x.dtype
         masters = (a.c_attn.w, a.c_attn.b, a.c_proj.w, a.c_proj.b, self.linear1.weight, self.linear1.bias,
                    self.linear2.weight, self.linear2.bias, self.norm1.weight, self.norm1.bias,
                    self.norm2.weight, self.norm2.bias)
-        shadows = (s.get(a.c_attn.w, dt, (d, 3 * d)), s.get(a.c_attn.b, dt), s.get(a.c_proj.w, dt, (d, d)),
-                   s.get(a.c_proj.b, dt), s.get(self.linear1.weight, dt), s.get(self.linear2.weight, dt),
-                   s.get(self.linear2.bias, dt))
+        W = BlockWeights(self._shadow, masters, self.n_state, dt)
         return ops.fused_decoder_block(x, self.heads, self.activation, self.drop.p, self.norm1.eps, self.training,
-                                       None, a.E, s.get(a.E, dt), masters, shadows)
+                                       None, a.E, self._shadow.get(a.E, dt), W)
 
 
 class RelativeTransformer(nn.Module):

@@ -213,6 +213,57 @@ def bias_act_bwd(dh, pre, act="gelu", p_drop=0.0, seed=0):
 
 
 # ---------------------------------------------------------------------------
+# bf16 MFMA GEMMs
+# ---------------------------------------------------------------------------
+def gemm_nt_supported(a: torch.Tensor, bt: torch.Tensor) -> bool:
+    """Shapes the hand-written NT kernel takes; anything else is a plain library GEMM (torch.mm)."""
+    return (a.dtype == torch.bfloat16 and bt.dtype == torch.bfloat16 and a.dim() == 2 and bt.dim() == 2
+            and a.shape[1] % 64 == 0 and a.is_contiguous() and bt.is_contiguous())
+
+
+def gemm_nt(a, bt, bias=None, res=None, act=None, p_drop=0.0, seed=0, n_pad_to=8):
+    """C = a[M,K] @ bt[N,K]^T (+ bias) (+ res); with act: returns (pre, dropout(act(pre)))."""
+    _need(a, "a", torch.bfloat16)
+    _need(bt, "bt", torch.bfloat16)
+    M, K = a.shape
+    N, K2 = bt.shape
+    if K != K2 or K % 64:
+        raise ValueError(f"gemm_nt: a {tuple(a.shape)} bt {tuple(bt.shape)}: K must match and be a multiple of 64")
+    if N % 8:
+        raise ValueError("gemm_nt: N must be a multiple of 8 (pad the weight)")
+    if bias is not None:
+        _need(bias, "bias", torch.float32)
+        if bias.numel() != N:
+            raise ValueError("gemm_nt: bias size")
+    if res is not None:
+        _need(res, "res", torch.bfloat16)
+        if res.shape != (M, N):
+            raise ValueError("gemm_nt: residual shape")
+    c = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    c2 = torch.empty_like(c) if act is not None else None
+    with _timed("gemm_nt"):
+        check(lib.mgx_gemm_nt_bf16(_p(a), _p(bt), _p(c), _p(c2), _p(bias), _p(res), M, N, K, K, K, N,
+                                   -1 if act is None else _ACT[act], float(p_drop), seed, _stream()), "mgx_gemm_nt_bf16")
+    return c if act is None else (c, c2)
+
+
+def gemm_tn(a, b, out_dtype=torch.float32):
+    """C[M,N] = a[K,M]^T @ b[K,N] (weight gradient), fp32 accumulation over a split K."""
+    _need(a, "a", torch.bfloat16)
+    _need(b, "b", torch.bfloat16)
+    K, M = a.shape
+    K2, N = b.shape
+    if K != K2 or M % 8 or N % 8:
+        raise ValueError(f"gemm_tn: a {tuple(a.shape)} b {tuple(b.shape)}: K must match, M and N multiples of 8")
+    ws_n = lib.mgx_gemm_tn_workspace_floats(M, N, K, None)
+    ws = torch.empty(ws_n, dtype=torch.float32, device=a.device)
+    c = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    with _timed("gemm_tn"):
+        check(lib.mgx_gemm_tn_bf16(_p(a), _p(b), _p(c), _p(ws), M, N, K, M, N, _dt(c), _stream()), "mgx_gemm_tn_bf16")
+    return c
+
+
+# ---------------------------------------------------------------------------
 # softmax cross-entropy
 # ---------------------------------------------------------------------------
 _XENT_SUMS = lib.mgx_xent_sums_len()
@@ -289,86 +340,117 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 # ---------------------------------------------------------------------------
 # whole post-LN decoder block as one autograd node
 # ---------------------------------------------------------------------------
+import os as _os
+
+# bf16 projections: "mgx" = hand-written MFMA GEMMs with fused epilogues, "torch" = library GEMMs
+GEMM_BACKEND = _os.environ.get("MGX_GEMM", "mgx")
+
+
+def _use_mgx_gemm(x2, d, ff):
+    return GEMM_BACKEND == "mgx" and x2.dtype == torch.bfloat16 and d % 64 == 0 and ff % 64 == 0
+
+
 class _DecoderBlock(torch.autograd.Function):
     """alibi_unified.py:86-95 / relative_transformer.py:77-86.
 
-    Inputs: x [B,S,d] in the compute dtype; fp32 master parameters (autograd
-    leaves) and their compute-dtype shadows (same tensors in fp32 mode).
-    GEMMs are plain library calls (torch.mm/addmm -> hipBLASLt); everything
-    between them is a libmgx kernel.
+    Inputs: x [B,S,d] in the compute dtype, the block's BlockWeights (compute-dtype shadows in
+    both orientations) and the fp32 master parameters (autograd leaves).  bf16: projections run on
+    the libmgx MFMA GEMMs (bias / bias+GELU+dropout / residual epilogues, fp32 weight gradients);
+    fp32 (parity mode) and shapes the kernels do not take use plain library GEMMs.
     """
 
     @staticmethod
-    def forward(ctx, x, cfg, slopes, E_master, E,
-                wqkv_m, bqkv_m, wp_m, bp_m, w1_m, b1_m, w2_m, b2_m, g1, be1, g2, be2,
-                wqkv, bqkv, wp, bp, w1, w2, b2):
+    def forward(ctx, x, cfg, slopes, E_master, E, W, *masters):
         n_heads, act, p_drop, eps, training = cfg
         B, S, d = x.shape
         T = B * S
         x2 = x.reshape(T, d)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
+        ff = W.m_w1.shape[0]
         p = p_drop if training else 0.0
         seed1 = new_seed() if p > 0 else 0
         seed2 = new_seed() if p > 0 else 0
-        qkv = torch.addmm(bqkv, x2, wqkv).view(B, S, 3 * d)
+        mgx = _use_mgx_gemm(x2, d, ff)
+        if mgx:
+            qkv = gemm_nt(x2, W.wqkv_t, W.m_bqkv).view(B, S, 3 * d)
+        else:
+            qkv = torch.addmm(W.bqkv, x2, W.wqkv).view(B, S, 3 * d)
         if E is None:
             a, lse = alibi_attn_fwd(qkv, slopes, n_heads)
         else:
             a, lse = rel_attn_fwd(qkv, E, n_heads)
         a2 = a.view(T, d)
-        pr = torch.addmm(bp, a2, wp)
-        h1, z1, mean1, rstd1 = ln_residual_fwd(pr, x2, g1, be1, eps, p, seed1)
-        u = torch.mm(h1, w1.t())
-        pre, hact = bias_act_fwd(u, b1_m, act, p, seed2)
-        v = torch.addmm(b2, hact, w2.t())
-        h2, z2, mean2, rstd2 = ln_residual_fwd(v, h1, g2, be2, eps)
-        ctx.save_for_backward(x2, qkv, a, lse, z1, mean1, rstd1, h1, pre, hact, z2, mean2, rstd2,
-                              slopes, E, wqkv, wp, w1, w2, g1, g2)
-        ctx.cfg = (n_heads, act, p, seed1, seed2, B, S, d)
+        pr = gemm_nt(a2, W.wp_t, W.m_bp) if mgx else torch.addmm(W.bp, a2, W.wp)
+        h1, z1, mean1, rstd1 = ln_residual_fwd(pr, x2, W.m_g1, W.m_be1, eps, p, seed1)
+        if mgx:
+            pre, hact = gemm_nt(h1, W.w1, W.m_b1, None, act, p, seed2)
+            v = gemm_nt(hact, W.w2, W.m_b2)
+        else:
+            u = torch.mm(h1, W.w1.t())
+            pre, hact = bias_act_fwd(u, W.m_b1, act, p, seed2)
+            v = torch.addmm(W.b2, hact, W.w2.t())
+        h2, z2, mean2, rstd2 = ln_residual_fwd(v, h1, W.m_g2, W.m_be2, eps)
+        ctx.save_for_backward(x2, qkv, a, lse, z1, mean1, rstd1, h1, pre, hact, z2, mean2, rstd2, slopes, E)
+        ctx.W = W
+        ctx.cfg = (n_heads, act, p, seed1, seed2, B, S, d, mgx)
         return h2.view(B, S, d)
 
     @staticmethod
     def backward(ctx, dh2):
-        (x2, qkv, a, lse, z1, mean1, rstd1, h1, pre, hact, z2, mean2, rstd2,
-         slopes, E, wqkv, wp, w1, w2, g1, g2) = ctx.saved_tensors
-        n_heads, act, p, seed1, seed2, B, S, d = ctx.cfg
+        x2, qkv, a, lse, z1, mean1, rstd1, h1, pre, hact, z2, mean2, rstd2, slopes, E = ctx.saved_tensors
+        W = ctx.W
+        n_heads, act, p, seed1, seed2, B, S, d, mgx = ctx.cfg
         T = B * S
         f32 = torch.float32
         dh2 = dh2.reshape(T, d).contiguous()
-        dz2, _, dg2, dbe2 = ln_residual_bwd(dh2, None, z2, mean2, rstd2, g2)
-        dw2 = torch.mm(dz2.t(), hact)                      # [d, ff]
+        dz2, _, dg2, dbe2 = ln_residual_bwd(dh2, None, z2, mean2, rstd2, W.m_g2)
         db2 = dz2.sum(0, dtype=f32)
-        dact = torch.mm(dz2, w2)                           # [T, ff]
+        if mgx:
+            dw2 = gemm_tn(dz2, hact)                       # [d, ff] fp32
+            dact = gemm_nt(dz2, W.w2_t)                    # [T, ff]
+        else:
+            dw2 = torch.mm(dz2.t(), hact)
+            dact = torch.mm(dz2, W.w2)
         dpre, db1 = bias_act_bwd(dact, pre, act, p, seed2)
-        dw1 = torch.mm(dpre.t(), h1)                       # [ff, d]
-        dh1 = torch.mm(dpre, w1)                           # [T, d]
-        dz1, da1, dg1, dbe1 = ln_residual_bwd(dh1, dz2, z1, mean1, rstd1, g1, p, seed1)
+        if mgx:
+            dw1 = gemm_tn(dpre, h1)                        # [ff, d]
+            dh1 = gemm_nt(dpre, W.w1_t)                    # [T, d]
+        else:
+            dw1 = torch.mm(dpre.t(), h1)
+            dh1 = torch.mm(dpre, W.w1)
+        dz1, da1, dg1, dbe1 = ln_residual_bwd(dh1, dz2, z1, mean1, rstd1, W.m_g1, p, seed1)
         a2 = a.view(T, d)
-        dwp = torch.mm(a2.t(), da1)                        # [d, d]
         dbp = da1.sum(0, dtype=f32)
-        da = torch.mm(da1, wp.t()).view(B, S, d)
+        if mgx:
+            dwp = gemm_tn(a2, da1)                         # [d, d]
+            da = gemm_nt(da1, W.wp).view(B, S, d)          # da1 @ wp^T
+        else:
+            dwp = torch.mm(a2.t(), da1)
+            da = torch.mm(da1, W.wp.t()).view(B, S, d)
         if E is None:
             dqkv = alibi_attn_bwd(da, qkv, a, lse, slopes, n_heads)
             dE = None
         else:
             dqkv, dE = rel_attn_bwd(da, qkv, a, lse, E, n_heads)
         dqkv2 = dqkv.view(T, 3 * d)
-        dwqkv = torch.mm(x2.t(), dqkv2)                    # [d, 3d]
         dbqkv = dqkv2.sum(0, dtype=f32)
-        dx = torch.addmm(dz1, dqkv2, wqkv.t()).view(B, S, d)
-        return (dx, None, None, dE, None,
-                dwqkv.unsqueeze(0), dbqkv, dwp.unsqueeze(0), dbp, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2,
-                None, None, None, None, None, None, None)
+        if mgx:
+            dwqkv = gemm_tn(x2, dqkv2)                     # [d, 3d]
+            dx = gemm_nt(dqkv2, W.wqkv, None, dz1).view(B, S, d)   # dqkv @ wqkv^T + dz1
+        else:
+            dwqkv = torch.mm(x2.t(), dqkv2)
+            dx = torch.addmm(dz1, dqkv2, W.wqkv.t()).view(B, S, d)
+        return (dx, None, None, dE, None, None,
+                dwqkv.unsqueeze(0), dbqkv, dwp.unsqueeze(0), dbp, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2)
 
 
-def fused_decoder_block(x, n_heads, act, p_drop, eps, training, slopes, E_master, E,
-                        masters, shadows):
-    """masters: (c_attn.w, c_attn.b, c_proj.w, c_proj.b, linear1.weight, linear1.bias, linear2.weight,
-    linear2.bias, norm1.weight, norm1.bias, norm2.weight, norm2.bias) fp32 parameters.
-    shadows: (wqkv [d,3d], bqkv, wp [d,d], bp, w1 [ff,d], w2 [d,ff], b2) in the compute dtype."""
+def fused_decoder_block(x, n_heads, act, p_drop, eps, training, slopes, E_master, E, W):
+    """W: base_layers.BlockWeights of the block (masters = c_attn.w, c_attn.b, c_proj.w, c_proj.b,
+    linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm1.weight, norm1.bias, norm2.weight,
+    norm2.bias)."""
     cfg = (n_heads, act, float(p_drop), float(eps), bool(training))
-    return _DecoderBlock.apply(x, cfg, slopes, E_master, E, *masters, *shadows)
+    return _DecoderBlock.apply(x, cfg, slopes, E_master, E, W, *W.masters)
 
 
 # ---------------------------------------------------------------------------

@@ -329,3 +329,76 @@ def test_bad_arguments_fail_loudly():
         ops.ln_residual_fwd(torch.zeros(4, 6).cuda(), None, torch.ones(6).cuda(), torch.zeros(6).cuda())  # d % 4
     with pytest.raises(ValueError):
         ops.alibi_attn_fwd(torch.zeros(1, 4, 25).cuda(), torch.ones(1).cuda(), 1)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 264, 128), (1000, 3072, 1024), (77, 624, 512), (512, 1024, 4096)])
+@pytest.mark.parametrize("epi", ["none", "bias", "bias_res", "gelu", "relu"])
+def test_gemm_nt(M, N, K, epi):
+    """Hand-written NT GEMM vs fp32 matmul on the bf16-rounded operands; asymmetric random data."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    bt = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    bias = torch.randn(N, generator=g) if epi != "none" else None
+    res = torch.randn(M, N, generator=g).bfloat16() if epi == "bias_res" else None
+    ref = a.float() @ bt.float().t()
+    if bias is not None:
+        ref = ref + bias
+    if res is not None:
+        ref = ref + res.float()
+    act = epi if epi in ("gelu", "relu") else None
+    out = ops.gemm_nt(a.cuda(), bt.cuda(), None if bias is None else bias.cuda(), None if res is None else res.cuda(), act)
+    if act is None:
+        assert gu.rel_err(out.float(), ref) < 1e-2
+    else:
+        pre, h = out
+        assert gu.rel_err(pre.float(), ref) < 1e-2
+        assert gu.rel_err(h.float(), O._ACT[act](pre.float().cpu())) < 1e-2
+
+
+def test_gemm_nt_exact_integers():
+    """Small-integer operands: every product and sum is exact in bf16/fp32, so any swapped fragment
+    index or k-order mismatch is an exact mismatch."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 512, 520, 192
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    bt = torch.randint(-3, 4, (N, K), generator=g).float()
+    out = ops.gemm_nt(a.bfloat16().cuda(), bt.bfloat16().cuda())
+    assert torch.equal(out.float().cpu(), (a @ bt.t()).bfloat16().float())
+
+
+def test_gemm_nt_dropout_matches_bias_act_mask():
+    """The fused epilogue drops exactly the elements mgx_bias_act_bwd regenerates from (seed, index)."""
+    ops = _ops()
+    M, N, K, p, seed = 256, 512, 64, 0.25, 987654321
+    a = torch.ones(M, K).bfloat16().cuda()
+    bt = (torch.ones(N, K) / K).bfloat16().cuda()
+    pre, h = ops.gemm_nt(a, bt, torch.zeros(N).cuda(), None, "relu", p, seed)
+    kept = h != 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 0.02
+    dpre, _ = ops.bias_act_bwd(torch.ones(M, N).bfloat16().cuda(), pre, "relu", p, seed)
+    assert torch.equal(dpre != 0, kept)
+
+
+@pytest.mark.parametrize("K,M,N", [(64, 256, 256), (1000, 264, 520), (8192, 1024, 3072), (333, 64, 128)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_gemm_tn(K, M, N, out_dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(K, M, generator=g).bfloat16()
+    b = (torch.randn(K, N, generator=g) / K ** 0.5).bfloat16()
+    ref = a.float().t() @ b.float()
+    out = ops.gemm_tn(a.cuda(), b.cuda(), out_dtype)
+    assert out.dtype == out_dtype
+    assert gu.rel_err(out.float(), ref) < (1e-4 if out_dtype == torch.float32 else 1e-2)
+
+
+def test_gemm_tn_exact_integers():
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    K, M, N = 700, 520, 264
+    a = torch.randint(-3, 4, (K, M), generator=g).float()
+    b = torch.randint(-3, 4, (K, N), generator=g).float()
+    out = ops.gemm_tn(a.bfloat16().cuda(), b.bfloat16().cuda(), torch.float32)
+    assert torch.equal(out.cpu(), a.t() @ b)
