@@ -23,9 +23,12 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // A + B
 constexpr int CPITCH = 64 * 2 + 16;               // epilogue staging: 64 bf16 per row + pad (16-B aligned)
 
 // ---- LDS images -----------------------------------------------------------------------------
-// K-contiguous operand tile [256 rows][64 k]: 8 chunks of 16 B per row
+// K-contiguous operand tile [256 rows][64 k] (NT): plain 128-byte rows, 16-byte chunk index XORed
+// with (row>>1)&7.  One LDS-DMA wave-instruction (1 KiB) = 8 whole rows = 8 full 128-byte cache
+// lines, each fetched by 8 adjacent lanes; ds_read_b128 row reads of 32 rows are conflict-free
+// (two rows per 256-byte bank row, 8 chunk slots each).
 __device__ __forceinline__ int img64_off(int row, int ch) {
-    return 1024 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+    return 1024 * (row >> 3) + 128 * (row & 7) + 16 * (ch ^ ((row >> 1) & 7));
 }
 // K-major operand tile [64 k rows][256 cols] as two [64][128] images (16 chunks per row each)
 __device__ __forceinline__ int img128_off(int row, int ch) {
@@ -86,7 +89,7 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // NT kernel
 // =============================================================================================
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + 8 * 256];   // + touch dump area
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, h5 = lane >> 5;
     const int wm = w >> 2, wn = w & 3;
@@ -104,15 +107,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int piece = 4 * w + i;                          // 8-row group of the tile
-        const int row = 8 * piece + ((lane >> 2) & 7);
-        const int ch = 4 * (lane >> 5) + ((lane & 3) ^ ((row >> 2) & 3));
+        const int row = 8 * piece + (lane >> 3);
+        const int ch = (lane & 7) ^ ((row >> 1) & 7);
         ap[i] = g.A + (long)min(m0 + row, g.M - 1) * g.lda + ch * 8;
         bp[i] = g.B + (long)min(n0 + row, g.N - 1) * g.ldb + ch * 8;
     }
     typedef __attribute__((address_space(3))) void lds_void;
+    const int nk_total = g.K / BK;
     auto stage = [&](int k0, int buf) {
 #ifdef MGX_GEMM_NOLOAD                      // timing experiment only: results are wrong
         if (k0 > 0) return;
+#endif
+#ifdef MGX_GEMM_SAMETILE                    // timing experiment only: every load re-reads K tile 0 (cache hits)
+        k0 = 0;
 #endif
         char* sa = smem + buf * STAGE_BYTES + 4096 * w;
 #pragma unroll
@@ -122,8 +129,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g) {
         }
     };
 
+    // L2 warm-up: every wave touches one dword of each 128-byte row segment of a K tile PF tiles ahead
+    // (64 rows per wave: waves 0-3 the A rows, 4-7 the Bt rows), so the LDS-DMA of that tile later hits
+    // this XCD's L2 instead of paying an HBM round trip with only ~1 K tile of flight time.
+    constexpr int PF = 4;   // (measured: no gain on MI355X at the training shapes; kept for experiments)
+    const bf16_t* tp = (w < 4) ? g.A + (long)min(m0 + 64 * w + lane, g.M - 1) * g.lda
+                               : g.B + (long)min(n0 + 64 * (w - 4) + lane, g.N - 1) * g.ldb;
+    auto touch = [&](int kt_ahead) {
+        // 4-byte LDS-DMA into a per-wave dump area: no VGPR destination, so nothing for the compiler to reuse
+        const bf16_t* q = tp + min(kt_ahead, nk_total - 1) * BK + 32;
+        __builtin_amdgcn_global_load_lds((const void*)q, (lds_void*)(smem + 2 * STAGE_BYTES + 256 * w), 4, 0, 0);
+    };
+
     // fragment read offsets: row l31 of a 32-row block, chunk 2*ks + h5
-    const int r0 = img64_off(l31, h5), r1 = img64_off(l31, 2 + h5);
+    int rk[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rk[ks] = img64_off(l31, 2 * ks + h5);
     const int a_base = 1024 * 4 * (4 * wm);            // wave's first 32-row block of A: 128*wm
     const int b_base = TILE_BYTES + 1024 * 4 * (2 * wn);
 
@@ -142,34 +163,48 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g) {
     // every SIMD always has one wave feeding it.  Raw s_barrier (no vmcnt drain): tile t+1's LDS-DMA
     // is issued two intervals before its first read and each wave waits for its own pieces
     // (vmcnt(0)) right before the barrier that precedes that read.
-    const int nk = g.K / BK;
+    const int nk = nk_total;
     const int grp = __builtin_amdgcn_readfirstlane(w) >> 2;
+    // vmcnt bookkeeping (in issue order): every stage() = 8 LDS-DMA pieces, always followed by one touch();
+    // a wave waits with vmcnt(1): all its pieces landed, the youngest touch may still be in flight.
     stage(0, 0);
-    if (grp == 1 && nk > 1) stage(BK, 1);
-    if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // tile 0 landed; tile 1's 8 pieces may still fly
+    touch(1);
+    if (grp == 1 && nk > 1) {
+        stage(BK, 1);
+        touch(2);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // tile 0 (and its touch) done
+    } else {
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    }
+    touch(3);
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();                  // stagger by one interval
     for (int kt = 0; kt < nk; ++kt) {
         const char* s = smem + (kt & 1) * STAGE_BYTES;
         // ---- READ interval
-        if (grp == 0 && kt + 1 < nk) stage((kt + 1) * BK, (kt + 1) & 1);
+        if (grp == 0 && kt + 1 < nk) {
+            stage((kt + 1) * BK, (kt + 1) & 1);
+            touch(kt + 1 + PF);
+        }
         bf16x8 bf[4][2], af[4][4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int ko = ((ks & 1) ? r1 : r0) + 512 * (ks >> 1);
+            const int ko = rk[ks];
 #pragma unroll
             for (int j = 0; j < 2; ++j) bf[ks][j] = lds16(s + b_base + 4096 * j + ko);
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[ks][i] = lds16(s + a_base + 4096 * i + ko);
         }
-        if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- MFMA interval
-        if (grp == 1 && kt + 2 < nk) stage((kt + 2) * BK, kt & 1);
+        if (grp == 1 && kt + 2 < nk) {
+            stage((kt + 2) * BK, kt & 1);
+            touch(kt + 2 + PF);
+        }
         __builtin_amdgcn_s_setprio(1);
         // the Bt rows go in as the MFMA "A" operand: D[row = n][col = m], so each lane (= one C row)
         // holds 4 consecutive n per register group
@@ -181,12 +216,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the last touch
 
     // ---- epilogue through LDS: wave-private [64 rows][64 cols] slab, two passes (mi pairs) ----
     char* cs = smem + w * (64 * CPITCH);

@@ -342,12 +342,20 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 # ---------------------------------------------------------------------------
 import os as _os
 
-# bf16 projections: "mgx" = hand-written MFMA GEMMs with fused epilogues, "torch" = library GEMMs
-GEMM_BACKEND = _os.environ.get("MGX_GEMM", "mgx")
+# bf16 projections.  "mgx": every projection on the hand-written MFMA GEMMs; "torch": every projection a
+# library GEMM (hipBLASLt); "auto" (default): per site, whichever measured faster on MI355X at the
+# training shapes (tools/gemm_bench.py): the MLP up-projection with its fused bias+GELU+dropout epilogue
+# and the c_proj weight gradient run on libmgx, the rest on the library.
+GEMM_BACKEND = _os.environ.get("MGX_GEMM", "auto")
+_AUTO_SITES = {"mlp1", "dwp"}
 
 
-def _use_mgx_gemm(x2, d, ff):
-    return GEMM_BACKEND == "mgx" and x2.dtype == torch.bfloat16 and d % 64 == 0 and ff % 64 == 0
+def _mgx_sites(x2, d, ff):
+    if x2.dtype != torch.bfloat16 or d % 64 or ff % 64 or GEMM_BACKEND == "torch":
+        return frozenset()
+    if GEMM_BACKEND == "mgx":
+        return frozenset({"qkv", "proj", "mlp1", "mlp2", "dw2", "dact", "dw1", "dh1", "dwp", "da", "dwqkv", "dx"})
+    return _AUTO_SITES
 
 
 class _DecoderBlock(torch.autograd.Function):
@@ -371,8 +379,8 @@ class _DecoderBlock(torch.autograd.Function):
         p = p_drop if training else 0.0
         seed1 = new_seed() if p > 0 else 0
         seed2 = new_seed() if p > 0 else 0
-        mgx = _use_mgx_gemm(x2, d, ff)
-        if mgx:
+        mgx = _mgx_sites(x2, d, ff)
+        if "qkv" in mgx:
             qkv = gemm_nt(x2, W.wqkv_t, W.m_bqkv).view(B, S, 3 * d)
         else:
             qkv = torch.addmm(W.bqkv, x2, W.wqkv).view(B, S, 3 * d)
@@ -381,15 +389,14 @@ class _DecoderBlock(torch.autograd.Function):
         else:
             a, lse = rel_attn_fwd(qkv, E, n_heads)
         a2 = a.view(T, d)
-        pr = gemm_nt(a2, W.wp_t, W.m_bp) if mgx else torch.addmm(W.bp, a2, W.wp)
+        pr = gemm_nt(a2, W.wp_t, W.m_bp) if "proj" in mgx else torch.addmm(W.bp, a2, W.wp)
         h1, z1, mean1, rstd1 = ln_residual_fwd(pr, x2, W.m_g1, W.m_be1, eps, p, seed1)
-        if mgx:
+        if "mlp1" in mgx:
             pre, hact = gemm_nt(h1, W.w1, W.m_b1, None, act, p, seed2)
-            v = gemm_nt(hact, W.w2, W.m_b2)
         else:
             u = torch.mm(h1, W.w1.t())
             pre, hact = bias_act_fwd(u, W.m_b1, act, p, seed2)
-            v = torch.addmm(W.b2, hact, W.w2.t())
+        v = gemm_nt(hact, W.w2, W.m_b2) if "mlp2" in mgx else torch.addmm(W.b2, hact, W.w2.t())
         h2, z2, mean2, rstd2 = ln_residual_fwd(v, h1, W.m_g2, W.m_be2, eps)
         ctx.save_for_backward(x2, qkv, a, lse, z1, mean1, rstd1, h1, pre, hact, z2, mean2, rstd2, slopes, E)
         ctx.W = W
@@ -406,28 +413,16 @@ class _DecoderBlock(torch.autograd.Function):
         dh2 = dh2.reshape(T, d).contiguous()
         dz2, _, dg2, dbe2 = ln_residual_bwd(dh2, None, z2, mean2, rstd2, W.m_g2)
         db2 = dz2.sum(0, dtype=f32)
-        if mgx:
-            dw2 = gemm_tn(dz2, hact)                       # [d, ff] fp32
-            dact = gemm_nt(dz2, W.w2_t)                    # [T, ff]
-        else:
-            dw2 = torch.mm(dz2.t(), hact)
-            dact = torch.mm(dz2, W.w2)
+        dw2 = gemm_tn(dz2, hact) if "dw2" in mgx else torch.mm(dz2.t(), hact)          # [d, ff]
+        dact = gemm_nt(dz2, W.w2_t) if "dact" in mgx else torch.mm(dz2, W.w2)           # [T, ff]
         dpre, db1 = bias_act_bwd(dact, pre, act, p, seed2)
-        if mgx:
-            dw1 = gemm_tn(dpre, h1)                        # [ff, d]
-            dh1 = gemm_nt(dpre, W.w1_t)                    # [T, d]
-        else:
-            dw1 = torch.mm(dpre.t(), h1)
-            dh1 = torch.mm(dpre, W.w1)
+        dw1 = gemm_tn(dpre, h1) if "dw1" in mgx else torch.mm(dpre.t(), h1)             # [ff, d]
+        dh1 = gemm_nt(dpre, W.w1_t) if "dh1" in mgx else torch.mm(dpre, W.w1)           # [T, d]
         dz1, da1, dg1, dbe1 = ln_residual_bwd(dh1, dz2, z1, mean1, rstd1, W.m_g1, p, seed1)
         a2 = a.view(T, d)
         dbp = da1.sum(0, dtype=f32)
-        if mgx:
-            dwp = gemm_tn(a2, da1)                         # [d, d]
-            da = gemm_nt(da1, W.wp).view(B, S, d)          # da1 @ wp^T
-        else:
-            dwp = torch.mm(a2.t(), da1)
-            da = torch.mm(da1, W.wp.t()).view(B, S, d)
+        dwp = gemm_tn(a2, da1) if "dwp" in mgx else torch.mm(a2.t(), da1)               # [d, d]
+        da = (gemm_nt(da1, W.wp) if "da" in mgx else torch.mm(da1, W.wp.t())).view(B, S, d)   # da1 @ wp^T
         if E is None:
             dqkv = alibi_attn_bwd(da, qkv, a, lse, slopes, n_heads)
             dE = None
@@ -435,11 +430,10 @@ class _DecoderBlock(torch.autograd.Function):
             dqkv, dE = rel_attn_bwd(da, qkv, a, lse, E, n_heads)
         dqkv2 = dqkv.view(T, 3 * d)
         dbqkv = dqkv2.sum(0, dtype=f32)
-        if mgx:
-            dwqkv = gemm_tn(x2, dqkv2)                     # [d, 3d]
-            dx = gemm_nt(dqkv2, W.wqkv, None, dz1).view(B, S, d)   # dqkv @ wqkv^T + dz1
+        dwqkv = gemm_tn(x2, dqkv2) if "dwqkv" in mgx else torch.mm(x2.t(), dqkv2)       # [d, 3d]
+        if "dx" in mgx:
+            dx = gemm_nt(dqkv2, W.wqkv, None, dz1).view(B, S, d)                        # dqkv @ wqkv^T + dz1
         else:
-            dwqkv = torch.mm(x2.t(), dqkv2)
             dx = torch.addmm(dz1, dqkv2, W.wqkv.t()).view(B, S, d)
         return (dx, None, None, dE, None, None,
                 dwqkv.unsqueeze(0), dbqkv, dwp.unsqueeze(0), dbp, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2)
