@@ -5,11 +5,13 @@
 // calls of DecoderBlock.forward (alibi_unified.py:90,92) plus their autograd.
 //
 // Tile 256 x 256 x 64, 8 waves as 2 (M) x 4 (N), each wave 128 x 64 = 4 x 2 accumulators of
-// v_mfma_f32_32x32x16_bf16 (128 accumulator registers).  Operand tiles are staged
-// global -> registers -> LDS, double-buffered (2 x 64 KiB), one barrier per K tile, the loads of
-// tile t+2 in flight under the MFMAs of tile t.  LDS image: 8-row x 32-column sub-tiles with an
-// XOR on the 16-byte chunk (same image as the attention kernels): conflict-free for the row reads
-// (NT) and for the ds_read_b64_tr_b16 transposed reads (TN).  The epilogue goes through LDS so
+// v_mfma_f32_32x32x16_bf16 (128 accumulator registers).  Operand tiles are staged by LDS-DMA
+// (global_load_lds_dwordx4, no VGPR round trip), double-buffered (2 x 64 KiB).  NT runs the two
+// waves of every SIMD half a K tile apart (one reads fragments while the other issues MFMAs, see
+// the main loop); TN uses one barrier per K tile.  LDS images: NT = 128-byte rows with the chunk
+// index XORed by (row>>1)&7 (full cache lines per DMA piece, conflict-free ds_read_b128); TN =
+// 8-row x 32-column sub-tiles with an XOR (the attention kernels' image) for conflict-free
+// ds_read_b64_tr_b16 transposed reads.  The epilogue goes through LDS so
 // that C is written in full 512-byte row segments with 16-byte stores, with bias / residual /
 // GELU / dropout applied on the way.  Workgroup ids are remapped so that each XCD works on a
 // contiguous run of tiles that share the A row panel (L2 reuse).
@@ -89,7 +91,7 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // NT kernel
 // =============================================================================================
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + 8 * 256];   // + touch dump area
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, h5 = lane >> 5;
     const int wm = w >> 2, wn = w & 3;
@@ -129,18 +131,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g) {
         }
     };
 
-    // L2 warm-up: every wave touches one dword of each 128-byte row segment of a K tile PF tiles ahead
-    // (64 rows per wave: waves 0-3 the A rows, 4-7 the Bt rows), so the LDS-DMA of that tile later hits
-    // this XCD's L2 instead of paying an HBM round trip with only ~1 K tile of flight time.
-    constexpr int PF = 4;   // (measured: no gain on MI355X at the training shapes; kept for experiments)
-    const bf16_t* tp = (w < 4) ? g.A + (long)min(m0 + 64 * w + lane, g.M - 1) * g.lda
-                               : g.B + (long)min(n0 + 64 * (w - 4) + lane, g.N - 1) * g.ldb;
-    auto touch = [&](int kt_ahead) {
-        // 4-byte LDS-DMA into a per-wave dump area: no VGPR destination, so nothing for the compiler to reuse
-        const bf16_t* q = tp + min(kt_ahead, nk_total - 1) * BK + 32;
-        __builtin_amdgcn_global_load_lds((const void*)q, (lds_void*)(smem + 2 * STAGE_BYTES + 256 * w), 4, 0, 0);
-    };
-
     // fragment read offsets: row l31 of a 32-row block, chunk 2*ks + h5
     int rk[4];
 #pragma unroll
@@ -165,27 +155,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g) {
     // (vmcnt(0)) right before the barrier that precedes that read.
     const int nk = nk_total;
     const int grp = __builtin_amdgcn_readfirstlane(w) >> 2;
-    // vmcnt bookkeeping (in issue order): every stage() = 8 LDS-DMA pieces, always followed by one touch();
-    // a wave waits with vmcnt(1): all its pieces landed, the youngest touch may still be in flight.
     stage(0, 0);
-    touch(1);
     if (grp == 1 && nk > 1) {
         stage(BK, 1);
-        touch(2);
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // tile 0 (and its touch) done
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // tile 0 landed; tile 1's 8 pieces may still fly
     } else {
-        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    touch(3);
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();                  // stagger by one interval
     for (int kt = 0; kt < nk; ++kt) {
         const char* s = smem + (kt & 1) * STAGE_BYTES;
         // ---- READ interval
-        if (grp == 0 && kt + 1 < nk) {
-            stage((kt + 1) * BK, (kt + 1) & 1);
-            touch(kt + 1 + PF);
-        }
         bf16x8 bf[4][2], af[4][4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -195,34 +176,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[ks][i] = lds16(s + a_base + 4096 * i + ko);
         }
-        if (grp == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        // group 0 issues its LDS-DMA behind its own fragment reads (their latency covers the issue cost)
+        if (grp == 0 && kt + 1 < nk) {
+            stage((kt + 1) * BK, (kt + 1) & 1);
+        }
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // ---- MFMA interval
-        if (grp == 1 && kt + 2 < nk) {
-            stage((kt + 2) * BK, kt & 1);
-            touch(kt + 2 + PF);
-        }
+        // ---- MFMA interval (group 1 interleaves its LDS-DMA issue with the MFMAs)
+        const bool g1stage = grp == 1 && kt + 2 < nk;
         __builtin_amdgcn_s_setprio(1);
         // the Bt rows go in as the MFMA "A" operand: D[row = n][col = m], so each lane (= one C row)
         // holds 4 consecutive n per register group
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+            if (g1stage) {
+                char* sa = smem + (kt & 1) * STAGE_BYTES + 4096 * w;
+                const int k0 = (kt + 2) * BK;
+                __builtin_amdgcn_global_load_lds((const void*)(ap[ks] + k0), (lds_void*)(sa + 1024 * ks), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const void*)(bp[ks] + k0), (lds_void*)(sa + TILE_BYTES + 1024 * ks), 16, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __builtin_amdgcn_s_setprio(0);
-        if (grp == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the last touch
 
     // ---- epilogue through LDS: wave-private [64 rows][64 cols] slab, two passes (mi pairs) ----
     char* cs = smem + w * (64 * CPITCH);
