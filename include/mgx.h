@@ -132,13 +132,23 @@ int mgx_softmax_xent_bwd(const void* logits, const long long* targets, const flo
  * (O(L^2) attention per step) by attention of R new query rows against a cache.
  *   q [B,R,H,dh]; kcache/vcache [B,H,Lmax,dh]; row r of q sits at absolute position
  *   pos0 + r and attends keys 0..pos0+r (the cache must already hold them);
- *   out [B,R,H,dh].  Wavefront-reduction softmax; HBM-bound.
+ *   out [B,R,H,dh], R <= 4.  Wavefront-reduction softmax; HBM-bound.  bf16 with dh in {64,128}
+ *   runs the streaming kernel (dot2 + DPP reductions, prefetched chunks); other cases the generic one.
  */
 int mgx_decode_attn(const void* q, const void* kcache, const void* vcache, const float* slopes,
                     void* out, int B, int R, int H, int dh, int Lmax, int pos0, int dtype, void* stream);
 /* Scatter R new k/v rows of qkv [B,R,3,H,dh] into the caches at positions pos0.. */
 int mgx_kv_append(const void* qkv, void* kcache, void* vcache,
                   int B, int R, int H, int dh, int Lmax, int pos0, int dtype, void* stream);
+
+/* Same two operations with the position read from device memory at execution time
+ * (*pos0_dev, one int32), so that a sampling step can be recorded once in a HIP graph and
+ * replayed while the position advances (inference_unified.py:14's loop variable).  A position
+ * with pos0 + R > Lmax cannot be rejected on the host: the kernels clamp it to Lmax - R. */
+int mgx_decode_attn_at(const void* q, const void* kcache, const void* vcache, const float* slopes,
+                       void* out, int B, int R, int H, int dh, int Lmax, const int* pos0_dev, int dtype, void* stream);
+int mgx_kv_append_at(const void* qkv, void* kcache, void* vcache,
+                     int B, int R, int H, int dh, int Lmax, const int* pos0_dev, int dtype, void* stream);
 
 /* ---- fused AdamW ---------------------------------------------------------------------
  * Replaces torch.optim.AdamW.step (build_everything_unified.py:42) for one flat

@@ -35,6 +35,8 @@ PROTOTYPES = {
     "mgx_softmax_xent_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _ll, _i, _vp]),
     "mgx_decode_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mgx_kv_append": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "mgx_decode_attn_at": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "mgx_kv_append_at": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "mgx_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _i, _vp]),
     "mgx_gemm_nt_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _vp]),
     "mgx_gemm_tn_workspace_floats": (_l, [_i, _i, _i, _vp]),

@@ -29,12 +29,15 @@ template <typename T>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc,
                                                            const T* __restrict__ vc, const float* __restrict__ slopes,
                                                            T* __restrict__ out, int R, int H, int dh, int Lmax,
-                                                           int pos0, float scale) {
+                                                           int pos0_host, const int* __restrict__ pos_dev,
+                                                           float scale) {
     constexpr int N = DVec<T>::N;
     typedef typename DVec<T>::type vec_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [4][MAXR][dh + 2]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = blockIdx.y, h = blockIdx.x;
+    int pos0 = pos_dev ? *pos_dev : pos0_host;
+    if (pos0 + R > Lmax) pos0 = Lmax - R;   // device-side positions cannot be checked on the host
     const int lpr = dh / N;              // lanes per key row (power of two, <= 64)
     const int rpl = 64 / lpr;            // key rows per wave-load
     const int sub = lane / lpr;          // which of the rpl rows this lane reads
@@ -155,9 +158,218 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     }
 }
 
+
+// ---- bf16 streaming kernel for dh 64 / 128 -------------------------------------------------
+// Same partition as above, tuned for HBM rate: U wave-loads of K and V in flight per wave and
+// the next chunk prefetched under the arithmetic of the current one; q.k on v_dot2_f32_bf16
+// (K is never widened), the in-row reduction on DPP adds (no LDS traffic), one online-softmax
+// rescale per chunk instead of per key, p.v on packed fp32 FMAs.
+__device__ __forceinline__ float dpp_add(float v, const int ctrl_tag) {
+    // ctrl_tag: 0 = xor 1, 1 = xor 2 (quad permutes), 2 = row_half_mirror, 3 = row_mirror
+    int y;
+    const int x = __float_as_int(v);
+    switch (ctrl_tag) {
+        case 0: y = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); break;
+        case 1: y = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true); break;
+        case 2: y = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true); break;
+        default: y = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true); break;
+    }
+    return v + __int_as_float(y);
+}
+
+#ifndef MGX_DEC_U
+#define MGX_DEC_U 4
+#endif
+#ifndef MGX_DEC_PF
+#define MGX_DEC_PF 0
+#endif
+template <int DH, int NW, int R>
+__global__ __launch_bounds__(NW * 64, 4) void decode_attn_bf16_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
+    const float* __restrict__ slopes, bf16_t* __restrict__ out, int H, int Lmax, int pos0_host,
+    const int* __restrict__ pos_dev, float scale_log2e) {
+    constexpr int LPR = DH / 8;          // lanes per key row: 16 (dh 128) or 8 (dh 64)
+    constexpr int RPL = 64 / LPR;        // key rows per wave-load
+    constexpr int U = MGX_DEC_U;         // wave-loads per chunk
+    constexpr float NEG = -1.0e30f;
+    constexpr float LOG2E = 1.4426950408889634f;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [NW][R][DH + 2]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.y, h = blockIdx.x;
+    const int sub = lane / LPR, ch = lane % LPR;
+    int pos0 = pos_dev ? *pos_dev : pos0_host;
+    if (pos0 + R > Lmax) pos0 = Lmax - R;
+    const float slope2 = (slopes ? slopes[h] : 0.f) * LOG2E;
+
+    bf16x2 qp[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(q + (((long)b * R + r) * H + h) * DH + ch * 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) qp[r][k] = bf16x2{t[2 * k], t[2 * k + 1]};
+    }
+    float m[R], l[R];
+    f32x2 acc[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        m[r] = NEG;
+        l[r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[r][k] = f32x2{0.f, 0.f};
+    }
+    const bf16_t* kb = kc + ((long)b * H + h) * Lmax * DH + ch * 8;
+    const bf16_t* vb = vc + ((long)b * H + h) * Lmax * DH + ch * 8;
+    const int nkeys = pos0 + R;
+    const int last = nkeys - 1;
+    constexpr int STEP = NW * U * RPL;
+
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 kcur[U], vcur[U], knxt[U], vnxt[U];
+    int j0 = w * U * RPL;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = min(j0 + u * RPL + sub, last);
+        kcur[u] = *reinterpret_cast<const u32x4*>(kb + (long)j * DH);
+        vcur[u] = *reinterpret_cast<const u32x4*>(vb + (long)j * DH);
+    }
+    for (; j0 < nkeys; j0 += STEP) {
+        if (MGX_DEC_PF && j0 + STEP < nkeys) {             // wave-uniform
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = min(j0 + STEP + u * RPL + sub, last);
+                knxt[u] = *reinterpret_cast<const u32x4*>(kb + (long)j * DH);
+                vnxt[u] = *reinterpret_cast<const u32x4*>(vb + (long)j * DH);
+            }
+        }
+        float s[R][U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * RPL + sub;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (r < R) {                 // uniform
+                    float a = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned kk = kcur[u][k];   // (bit_cast of a vector-element lvalue reads element 0)
+                        a = __builtin_amdgcn_fdot2_f32_bf16(qp[r][k], __builtin_bit_cast(bf16x2, kk), a, false);
+                    }
+                    a = dpp_add(a, 0);
+                    a = dpp_add(a, 1);
+                    a = dpp_add(a, 2);
+                    if (LPR == 16) a = dpp_add(a, 3);
+                    const int i = pos0 + r;
+                    a = fmaf(a, scale_log2e, slope2 * (float)(j - i));
+                    s[r][u] = (j > i || j > last) ? NEG : a;   // causal, and rows clamped past the end
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (r < R) {
+                float mx = s[r][0];
+#pragma unroll
+                for (int u = 1; u < U; ++u) mx = fmaxf(mx, s[r][u]);
+                const float mn = fmaxf(m[r], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m[r] - mn);
+                m[r] = mn;
+                float p[U], ps = 0.f;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    p[u] = (s[r][u] <= NEG) ? 0.f : __builtin_amdgcn_exp2f(s[r][u] - mn);
+                    ps += p[u];
+                }
+                l[r] = fmaf(l[r], alpha, ps);
+                const f32x2 al = {alpha, alpha};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[r][k] *= al;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const f32x2 pp = {p[u], p[u]};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned x = vcur[u][k];
+                        const f32x2 vv = {__uint_as_float(x << 16), __uint_as_float(x & 0xFFFF0000u)};
+                        acc[r][k] = __builtin_elementwise_fma(pp, vv, acc[r][k]);
+                    }
+                }
+            }
+        }
+        if (MGX_DEC_PF) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                kcur[u] = knxt[u];
+                vcur[u] = vnxt[u];
+            }
+        } else if (j0 + STEP < nkeys) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = min(j0 + STEP + u * RPL + sub, last);
+                kcur[u] = *reinterpret_cast<const u32x4*>(kb + (long)j * DH);
+                vcur[u] = *reinterpret_cast<const u32x4*>(vb + (long)j * DH);
+            }
+        }
+    }
+    // merge the RPL lane groups of this wave (base-2 domain)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (r < R) {
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) {
+                const float m2 = __shfl_xor(m[r], o, 64);
+                const float l2 = __shfl_xor(l[r], o, 64);
+                const float mn = fmaxf(m[r], m2);
+                const float a1 = __builtin_amdgcn_exp2f(m[r] - mn);
+                const float a2 = __builtin_amdgcn_exp2f(m2 - mn);
+                l[r] = l[r] * a1 + l2 * a2;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float o0 = __shfl_xor(acc[r][k][0], o, 64);
+                    const float o1 = __shfl_xor(acc[r][k][1], o, 64);
+                    acc[r][k][0] = acc[r][k][0] * a1 + o0 * a2;
+                    acc[r][k][1] = acc[r][k][1] * a1 + o1 * a2;
+                }
+                m[r] = mn;
+            }
+        }
+    }
+    constexpr int ldw = DH + 2;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (r < R && sub == 0) {
+            float* dst = smem + ((size_t)w * R + r) * ldw;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dst[ch * 8 + 2 * k] = acc[r][k][0];
+                dst[ch * 8 + 2 * k + 1] = acc[r][k][1];
+            }
+            if (ch == 0) {
+                dst[DH] = m[r];
+                dst[DH + 1] = l[r];
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < R * DH; e += NW * 64) {
+        const int r = e / DH, d = e - r * DH;
+        float mm = NEG;
+        for (int ww = 0; ww < NW; ++ww) mm = fmaxf(mm, smem[((size_t)ww * R + r) * ldw + DH]);
+        float num = 0.f, den = 0.f;
+        for (int ww = 0; ww < NW; ++ww) {
+            const float* src = smem + ((size_t)ww * R + r) * ldw;
+            const float a = __builtin_amdgcn_exp2f(src[DH] - mm);
+            num = fmaf(src[d], a, num);
+            den = fmaf(src[DH + 1], a, den);
+        }
+        out[(((long)b * R + r) * H + h) * DH + d] = (bf16_t)(num / den);
+    }
+}
+
 template <typename T>
 __global__ void kv_append_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc, int B, int R,
-                                 int H, int dh, int Lmax, int pos0) {
+                                 int H, int dh, int Lmax, int pos0_host, const int* __restrict__ pos_dev) {
+    int pos0 = pos_dev ? *pos_dev : pos0_host;
+    if (pos0 + R > Lmax) pos0 = Lmax - R;
     const long n = (long)B * R * H * dh;
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -175,47 +387,104 @@ __global__ void kv_append_kernel(const T* __restrict__ qkv, T* __restrict__ kc, 
 
 }  // namespace
 
-extern "C" int mgx_decode_attn(const void* q, const void* kcache, const void* vcache, const float* slopes, void* out,
-                               int B, int R, int H, int dh, int Lmax, int pos0, int dtype, void* stream) {
+namespace {
+
+int decode_attn_impl(const void* q, const void* kcache, const void* vcache, const float* slopes, void* out, int B, int R,
+                     int H, int dh, int Lmax, int pos0, const int* pos_dev, int dtype, void* stream) {
     MGX_REQUIRE(q && kcache && vcache && out, MGX_EINVAL, "mgx_decode_attn: null pointer");
     MGX_REQUIRE(B > 0 && H > 0 && dh > 0 && R >= 1 && R <= MAXR, MGX_EINVAL, "mgx_decode_attn: B=%d R=%d H=%d dh=%d", B,
                 R, H, dh);
     MGX_REQUIRE(dtype == MGX_F32 || dtype == MGX_BF16, MGX_EINVAL, "mgx_decode_attn: bad dtype %d", dtype);
-    MGX_REQUIRE(pos0 >= 0 && pos0 + R <= Lmax, MGX_EINVAL, "mgx_decode_attn: pos0=%d R=%d beyond Lmax=%d", pos0, R, Lmax);
+    MGX_REQUIRE(R <= Lmax, MGX_EINVAL, "mgx_decode_attn: R=%d beyond Lmax=%d", R, Lmax);
+    MGX_REQUIRE(pos_dev || (pos0 >= 0 && pos0 + R <= Lmax), MGX_EINVAL, "mgx_decode_attn: pos0=%d R=%d beyond Lmax=%d",
+                pos0, R, Lmax);
     const int N = dtype == MGX_F32 ? 4 : 8;
     const int lpr = dh / N;
     MGX_REQUIRE(dh % N == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0, MGX_EUNSUPPORTED,
                 "mgx_decode_attn: head dim %d must be a power of two in [%d, %d]", dh, N, 64 * N);
     MGX_REQUIRE(B <= 65535, MGX_EUNSUPPORTED, "mgx_decode_attn: B too large");
     const float scale = 1.0f / sqrtf((float)dh);
-    const size_t smem = (size_t)4 * MAXR * (dh + 2) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(H, B);
+    if (dtype == MGX_BF16 && (dh == 64 || dh == 128)) {
+        // 512 workgroups of 8 waves fill the chip (2 per CU); smaller launches get 16 waves each
+        const bool wide = (long)B * H < 512;
+        const int nw = wide ? 16 : 8;
+        const size_t smem = (size_t)nw * R * (dh + 2) * sizeof(float);
+        const float sl2 = scale * 1.4426950408889634f;
+#define MGX_DECODE_LAUNCH(DH_, NW_, R_)                                                                             \
+    hipLaunchKernelGGL((decode_attn_bf16_kernel<DH_, NW_, R_>), grid, dim3(NW_ * 64), smem, st, (const bf16_t*)q,    \
+                       (const bf16_t*)kcache, (const bf16_t*)vcache, slopes, (bf16_t*)out, H, Lmax, pos0, pos_dev,   \
+                       sl2)
+#define MGX_DECODE_R(DH_, NW_)                      \
+    switch (R) {                                    \
+        case 1: MGX_DECODE_LAUNCH(DH_, NW_, 1); break; \
+        case 2: MGX_DECODE_LAUNCH(DH_, NW_, 2); break; \
+        case 3: MGX_DECODE_LAUNCH(DH_, NW_, 3); break; \
+        default: MGX_DECODE_LAUNCH(DH_, NW_, 4); break; \
+    }
+        if (dh == 128) {
+            if (wide) MGX_DECODE_R(128, 16) else MGX_DECODE_R(128, 8)
+        } else {
+            if (wide) MGX_DECODE_R(64, 16) else MGX_DECODE_R(64, 8)
+        }
+#undef MGX_DECODE_R
+#undef MGX_DECODE_LAUNCH
+        MGX_CHECK_LAUNCH("decode_attn_bf16");
+        return MGX_OK;
+    }
+    const size_t smem = (size_t)4 * MAXR * (dh + 2) * sizeof(float);
     if (dtype == MGX_F32)
         hipLaunchKernelGGL((decode_attn_kernel<float>), grid, dim3(256), smem, st, (const float*)q,
-                           (const float*)kcache, (const float*)vcache, slopes, (float*)out, R, H, dh, Lmax, pos0, scale);
+                           (const float*)kcache, (const float*)vcache, slopes, (float*)out, R, H, dh, Lmax, pos0,
+                           pos_dev, scale);
     else
         hipLaunchKernelGGL((decode_attn_kernel<bf16_t>), grid, dim3(256), smem, st, (const bf16_t*)q,
                            (const bf16_t*)kcache, (const bf16_t*)vcache, slopes, (bf16_t*)out, R, H, dh, Lmax, pos0,
-                           scale);
+                           pos_dev, scale);
     MGX_CHECK_LAUNCH("decode_attn");
     return MGX_OK;
 }
 
-extern "C" int mgx_kv_append(const void* qkv, void* kcache, void* vcache, int B, int R, int H, int dh, int Lmax,
-                             int pos0, int dtype, void* stream) {
+int kv_append_impl(const void* qkv, void* kcache, void* vcache, int B, int R, int H, int dh, int Lmax, int pos0,
+                   const int* pos_dev, int dtype, void* stream) {
     MGX_REQUIRE(qkv && kcache && vcache, MGX_EINVAL, "mgx_kv_append: null pointer");
-    MGX_REQUIRE(B > 0 && R > 0 && H > 0 && dh > 0, MGX_EINVAL, "mgx_kv_append: bad shape");
-    MGX_REQUIRE(pos0 >= 0 && pos0 + R <= Lmax, MGX_EINVAL, "mgx_kv_append: pos0=%d R=%d beyond Lmax=%d", pos0, R, Lmax);
+    MGX_REQUIRE(B > 0 && R > 0 && H > 0 && dh > 0 && R <= Lmax, MGX_EINVAL, "mgx_kv_append: bad shape");
+    MGX_REQUIRE(pos_dev || (pos0 >= 0 && pos0 + R <= Lmax), MGX_EINVAL, "mgx_kv_append: pos0=%d R=%d beyond Lmax=%d",
+                pos0, R, Lmax);
     MGX_REQUIRE(dtype == MGX_F32 || dtype == MGX_BF16, MGX_EINVAL, "mgx_kv_append: bad dtype %d", dtype);
     const long n = (long)B * R * H * dh;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MGX_F32)
         hipLaunchKernelGGL((kv_append_kernel<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           (const float*)qkv, (float*)kcache, (float*)vcache, B, R, H, dh, Lmax, pos0);
+                           (const float*)qkv, (float*)kcache, (float*)vcache, B, R, H, dh, Lmax, pos0, pos_dev);
     else
         hipLaunchKernelGGL((kv_append_kernel<bf16_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           (const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache, B, R, H, dh, Lmax, pos0);
+                           (const bf16_t*)qkv, (bf16_t*)kcache, (bf16_t*)vcache, B, R, H, dh, Lmax, pos0, pos_dev);
     MGX_CHECK_LAUNCH("kv_append");
     return MGX_OK;
+}
+
+}  // namespace
+
+extern "C" int mgx_decode_attn(const void* q, const void* kcache, const void* vcache, const float* slopes, void* out,
+                               int B, int R, int H, int dh, int Lmax, int pos0, int dtype, void* stream) {
+    return decode_attn_impl(q, kcache, vcache, slopes, out, B, R, H, dh, Lmax, pos0, nullptr, dtype, stream);
+}
+
+extern "C" int mgx_decode_attn_at(const void* q, const void* kcache, const void* vcache, const float* slopes, void* out,
+                                  int B, int R, int H, int dh, int Lmax, const int* pos0_dev, int dtype, void* stream) {
+    MGX_REQUIRE(pos0_dev, MGX_EINVAL, "mgx_decode_attn_at: null position pointer");
+    return decode_attn_impl(q, kcache, vcache, slopes, out, B, R, H, dh, Lmax, 0, pos0_dev, dtype, stream);
+}
+
+extern "C" int mgx_kv_append(const void* qkv, void* kcache, void* vcache, int B, int R, int H, int dh, int Lmax,
+                             int pos0, int dtype, void* stream) {
+    return kv_append_impl(qkv, kcache, vcache, B, R, H, dh, Lmax, pos0, nullptr, dtype, stream);
+}
+
+extern "C" int mgx_kv_append_at(const void* qkv, void* kcache, void* vcache, int B, int R, int H, int dh, int Lmax,
+                                const int* pos0_dev, int dtype, void* stream) {
+    MGX_REQUIRE(pos0_dev, MGX_EINVAL, "mgx_kv_append_at: null position pointer");
+    return kv_append_impl(qkv, kcache, vcache, B, R, H, dh, Lmax, 0, pos0_dev, dtype, stream);
 }

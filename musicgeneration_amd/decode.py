@@ -14,6 +14,8 @@ Decode is partitioned by batch only (replicas; no collective).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -36,24 +38,32 @@ class KVCacheDecoder:
         self.caches = [(torch.zeros(batch, H, max_len, dh, dtype=self.dtype, device=self.device),
                         torch.zeros(batch, H, max_len, dh, dtype=self.dtype, device=self.device))
                        for _ in model.decoder_layers]
+        with torch.no_grad():
+            self._head_wb = tuple(t.detach() for t in model.head_weights(self.dtype))   # cast once per decoder
 
     @torch.no_grad()
-    def rows(self, tokens: torch.Tensor, pos0: int) -> torch.Tensor:
+    def rows(self, tokens: torch.Tensor, pos0) -> torch.Tensor:
         """Run token rows at absolute positions pos0.. through every layer.
 
         tokens: [B,R] (unified) or [B,3,R] (separated).  Their K/V are written
         into the caches at pos0..pos0+R-1 (overwriting provisional entries).
         R <= 4 uses the decode kernel; longer runs must start at pos0 == 0
         (prefill with the flash kernel).  Returns head logits for all R rows.
+        pos0 is an int, or a one-element int32 GPU tensor read by the kernels at
+        execution time (graph replay; R <= 4 only).
         """
         m = self.model
         dt = self.dtype
         h = m.embed_tokens(tokens, dt)
         B, R, d = h.shape
-        if pos0 + R > self.max_len:
-            raise ValueError("rows beyond the cache length")
-        if R > 4 and pos0 != 0:
-            raise ValueError("prefill (more than 4 rows) must start at position 0")
+        if isinstance(pos0, torch.Tensor):
+            if R > 4:
+                raise ValueError("a device-side position needs R <= 4")
+        else:
+            if pos0 + R > self.max_len:
+                raise ValueError("rows beyond the cache length")
+            if R > 4 and pos0 != 0:
+                raise ValueError("prefill (more than 4 rows) must start at position 0")
         T = B * R
         for layer, (kc, vc) in zip(m.decoder_layers, self.caches):
             W = layer.weights(dt)
@@ -74,7 +84,64 @@ class KVCacheDecoder:
             h2, _, _, _ = ops.ln_residual_fwd(v, h1, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps, save=False)
             h = h2.view(B, R, d)
         hn, _, _, _ = ops.ln_residual_fwd(h.reshape(T, d), None, m.norm.g, m.norm.b, m.norm.epsilon, save=False)
-        return m.head(hn.view(B, R, d))
+        return m.head(hn.view(B, R, d), self._head_wb)
+
+
+class GraphedSampler:
+    """One sampling step of the reference loop (inference_unified.py:14-20) recorded as a HIP graph.
+
+    The step reads its position from device memory (mgx_*_at entry points), gathers the three
+    token rows i-1, i, i+1 from `seq`, runs them against the caches, draws token i (greedy) and
+    scatters it into `seq`, then advances the position: replaying the graph L-2 times is the whole
+    loop, with no host round trip and ~70 kernel launches per step folded into one submission.
+    Stochastic sampling keeps the draw outside the graph (generator state is host-side).
+    """
+
+    def __init__(self, dec: KVCacheDecoder, seq: torch.Tensor, first: int, deterministic: bool):
+        self.dec, self.seq, self.det = dec, seq, deterministic
+        self.separated = seq.dim() == 3
+        dev = seq.device
+        self.pos = torch.full((1,), first - 1, dtype=torch.int32, device=dev)   # position of row 0 = i-1
+        self.off = torch.arange(3, device=dev)
+        self.logits = None
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):            # warm-up outside capture (library handles, workspaces)
+            keep = seq.clone()
+            self._body()
+            seq.copy_(keep)                      # the warm-up must not leave its token behind: the real
+            self.pos.fill_(first - 1)            # first step has to see the stale contents of position i
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+
+    def _body(self):
+        seq = self.seq
+        idx = (self.pos.long() + self.off)                       # i-1, i, i+1
+        tok = seq.index_select(-1, idx)
+        out = self.dec.rows(tok, self.pos)
+        if self.separated:
+            self.logits = [h[:, 2].float() for h in out]
+        else:
+            self.logits = out[:, 2].float()
+        if self.det:
+            self._write()
+        self.pos.add_(1)
+
+    def _write(self, at=None):
+        seq = self.seq
+        at = (self.pos.long() + 1) if at is None else at         # i
+        if self.separated:
+            r = torch.stack([_draw(h, self.det) for h in self.logits], -1).to(seq.dtype)     # [B,3]
+            seq.index_copy_(2, at, r.unsqueeze(-1))
+        else:
+            seq.index_copy_(1, at, _draw(self.logits, self.det).to(seq.dtype).unsqueeze(-1))
+
+    def step(self):
+        self.graph.replay()
+        if not self.det:
+            self._write(at=self.pos.long())      # the graph already advanced the position by one
 
 
 def _draw(logits_row: torch.Tensor, deterministic: bool) -> torch.Tensor:
@@ -85,11 +152,14 @@ def _draw(logits_row: torch.Tensor, deterministic: bool) -> torch.Tensor:
 
 @torch.no_grad()
 def sample_next_plus_one(model, seq: torch.Tensor, idx: int = 1, deterministic: bool = False,
-                         progress=None) -> torch.Tensor:
+                         progress=None, use_graph=None) -> torch.Tensor:
     """KV-cached equivalent of the reference `inference` loops; mutates and returns `seq`.
 
     seq [B,L] (unified) or [B,3,L] (separated), int32 or int64, on the GPU.
+    use_graph: replay the step as a HIP graph (default: env MGX_DECODE_GRAPH, on).
     """
+    if use_graph is None:
+        use_graph = os.environ.get("MGX_DECODE_GRAPH", "1") != "0"
     separated = seq.dim() == 3
     L = seq.shape[-1]
     B = seq.shape[0]
@@ -103,6 +173,13 @@ def sample_next_plus_one(model, seq: torch.Tensor, idx: int = 1, deterministic: 
     steps = range(idx, L - 1)
     if progress is not None:
         steps = progress(steps)
+    if use_graph and len(range(idx, L - 1)) > 0:
+        if not seq.is_contiguous():
+            raise ValueError("seq must be contiguous")
+        g = GraphedSampler(dec, seq, idx, deterministic)
+        for _ in steps:
+            g.step()
+        return seq
     for i in steps:
         logits = dec.rows(sl(i - 1, i + 2), i - 1)        # rows i-1 (final), i, i+1 (provisional)
         if separated:

@@ -75,10 +75,14 @@ class AlibiTransformer(nn.Module):
                        F.embedding(x[:, 2], self.embed_duration.weight)], dim=-1)
         return h.to(dtype)
 
-    def head(self, h):
-        dt = h.dtype
+    def head_weights(self, dt):
+        """The three output projections stacked into one [92+130+203, d] GEMM operand, in dtype dt."""
         w = torch.cat([self.proj_note.weight, self.proj_velocity.weight, self.proj_duration.weight], 0).to(dt)
         b = torch.cat([self.proj_note.bias, self.proj_velocity.bias, self.proj_duration.bias], 0).to(dt)
+        return w, b
+
+    def head(self, h, wb=None):
+        w, b = wb if wb is not None else self.head_weights(h.dtype)
         packed = F.linear(h, w, b)
         return SeparatedLogits(packed, (self.vocab_note, self.vocab_velocity, self.vocab_duration))
 

@@ -158,11 +158,15 @@ class AlibiTransformer(nn.Module):
     def embed_tokens(self, x, dtype):
         return F.embedding(x, self.embed.weight).to(dtype)
 
-    def head(self, h):
-        dt = h.dtype
+    def head_weights(self, dt):
+        """(weight, bias) of the output projection in dtype dt (a cast copy unless fp32)."""
         if dt == torch.float32:
-            return F.linear(h, self.proj_class.weight, self.proj_class.bias)
-        return F.linear(h, self.proj_class.weight.to(dt), self.proj_class.bias.to(dt))
+            return self.proj_class.weight, self.proj_class.bias
+        return self.proj_class.weight.to(dt), self.proj_class.bias.to(dt)
+
+    def head(self, h, wb=None):
+        w, b = wb if wb is not None else self.head_weights(h.dtype)
+        return F.linear(h, w, b)
 
     def forward(self, x: torch.Tensor):
         """x [B,S] int32/int64 -> logits [B,S,vocab] in the compute dtype (alibi_unified.py:124-138)."""

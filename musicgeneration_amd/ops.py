@@ -450,8 +450,15 @@ def fused_decoder_block(x, n_heads, act, p_drop, eps, training, slopes, E_master
 # ---------------------------------------------------------------------------
 # decode
 # ---------------------------------------------------------------------------
-def kv_append(qkv, kcache, vcache, pos0: int):
-    """qkv [B,R,3*d]; caches [B,H,Lmax,dh]."""
+def _dev_pos(pos0, like):
+    if pos0.dtype != torch.int32 or pos0.numel() != 1 or pos0.device != like.device:
+        raise ValueError("a device-side position must be one int32 on the tensors' GPU")
+    return _p(pos0)
+
+
+def kv_append(qkv, kcache, vcache, pos0):
+    """qkv [B,R,3*d]; caches [B,H,Lmax,dh].  pos0: int, or a 1-element int32 GPU tensor read at
+    execution time (HIP-graph replay)."""
     _need(qkv, "qkv")
     _need(kcache, "kcache", qkv.dtype)
     _need(vcache, "vcache", qkv.dtype)
@@ -459,12 +466,16 @@ def kv_append(qkv, kcache, vcache, pos0: int):
     Bc, H, Lmax, dh = kcache.shape
     if Bc != B or 3 * H * dh != d3 or vcache.shape != kcache.shape:
         raise ValueError("kv_append shape mismatch")
+    if isinstance(pos0, torch.Tensor):
+        check(lib.mgx_kv_append_at(_p(qkv), _p(kcache), _p(vcache), B, R, H, dh, Lmax, _dev_pos(pos0, qkv), _dt(qkv),
+                                   _stream()), "mgx_kv_append_at")
+        return
     check(lib.mgx_kv_append(_p(qkv), _p(kcache), _p(vcache), B, R, H, dh, Lmax, pos0, _dt(qkv), _stream()),
           "mgx_kv_append")
 
 
-def decode_attn(q, kcache, vcache, slopes, pos0: int):
-    """q [B,R,H*dh] rows at absolute positions pos0..pos0+R-1 -> out [B,R,H*dh]."""
+def decode_attn(q, kcache, vcache, slopes, pos0):
+    """q [B,R,H*dh] rows at absolute positions pos0..pos0+R-1 -> out [B,R,H*dh] (pos0 as in kv_append)."""
     _need(q, "q")
     _need(kcache, "kcache", q.dtype)
     _need(vcache, "vcache", q.dtype)
@@ -473,6 +484,10 @@ def decode_attn(q, kcache, vcache, slopes, pos0: int):
     if Bc != B or H * dh != d or vcache.shape != kcache.shape:
         raise ValueError("decode_attn shape mismatch")
     out = torch.empty_like(q)
+    if isinstance(pos0, torch.Tensor):
+        check(lib.mgx_decode_attn_at(_p(q), _p(kcache), _p(vcache), _p(slopes), _p(out), B, R, H, dh, Lmax,
+                                     _dev_pos(pos0, q), _dt(q), _stream()), "mgx_decode_attn_at")
+        return out
     with _timed("decode_attn"):
         check(lib.mgx_decode_attn(_p(q), _p(kcache), _p(vcache), _p(slopes), _p(out), B, R, H, dh, Lmax, pos0, _dt(q),
                                   _stream()), "mgx_decode_attn")

@@ -301,6 +301,40 @@ def test_decode_attention(dtype, B, H, dh, R, pos0):
     assert gu.rel_err(out.float(), ref) < tol
 
 
+@pytest.mark.parametrize("B,H,dh,R,pos0", [(64, 8, 128, 3, 700), (2, 8, 128, 3, 0), (3, 8, 64, 2, 1), (64, 8, 64, 4, 129),
+                                           (1, 8, 128, 3, 2045)])
+def test_decode_attention_streaming_bf16(B, H, dh, R, pos0):
+    """The bf16 streaming kernel (both workgroup widths, every R), host- and device-side positions,
+    against full causal attention in fp32 on the same bf16-rounded inputs."""
+    ops = _ops()
+    L = pos0 + R
+    Lmax = L + 3
+    d = H * dh
+    g = torch.Generator().manual_seed(pos0 + dh + B)
+    qkv = torch.randn(B, L, 3 * d, generator=g).to(torch.bfloat16).cuda()
+    slopes = torch.tensor(O.alibi_slopes(H), dtype=torch.float32).cuda()
+    # fp32 reference on the GPU (torch ops only; the CPU oracle is too slow at B=64)
+    q, k, v = (t.view(B, L, H, dh).transpose(1, 2).float() for t in qkv.split(d, -1))
+    idx = torch.arange(L, device="cuda")
+    bias = slopes.view(H, 1, 1) * (idx.view(1, 1, L) - idx.view(1, L, 1))
+    sc = q[:, :, pos0:] @ k.transpose(-1, -2) / dh ** 0.5 + bias[:, pos0:]
+    sc = sc.masked_fill(idx.view(1, 1, 1, L) > idx[pos0:].view(1, 1, R, 1), float("-inf"))
+    ref = (sc.softmax(-1) @ v).transpose(1, 2).reshape(B, R, d)
+    kc = torch.zeros(B, H, Lmax, dh, dtype=torch.bfloat16).cuda()
+    vc = torch.zeros_like(kc)
+    if pos0 > 0:
+        ops.kv_append(qkv[:, :pos0].contiguous(), kc, vc, 0)
+    pos_dev = torch.tensor([pos0], dtype=torch.int32).cuda()
+    ops.kv_append(qkv[:, pos0:].contiguous(), kc, vc, pos_dev)
+    assert torch.equal(kc[:, :, :L], qkv[:, :, d:2 * d].view(B, L, H, dh).transpose(1, 2))
+    qn = qkv[:, pos0:, :d].contiguous()
+    out = ops.decode_attn(qn, kc, vc, slopes, pos0)
+    out_dev = ops.decode_attn(qn, kc, vc, slopes, pos_dev)
+    assert torch.equal(out, out_dev)
+    assert gu.rel_err(out.float(), ref) < BF16_TOL
+    assert float((out.float() - ref).abs().max()) < 0.03 * float(ref.abs().max())
+
+
 def test_adamw_matches_torch():
     ops = _ops()
     g = torch.Generator().manual_seed(9)

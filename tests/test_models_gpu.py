@@ -239,6 +239,27 @@ def test_decode_matches_full_forward_long():
     assert gu.rel_err(part, full[:, 40:43]) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_graphed_decode_equals_eager(dtype):
+    """The HIP-graph replay of the sampling step (device-side position) produces exactly the
+    tokens of the step-by-step loop, greedy, at a kernel-shaped config."""
+    from musicgeneration_amd.model_baseline.alibi_unified import AlibiTransformer
+    from musicgeneration_amd.decode import sample_next_plus_one
+    torch.manual_seed(5)
+    m = AlibiTransformer(vocab=618, embed_dim=512, n_layers=2, n_heads=4, max_sequence=512, proj_forward=1024,
+                         dropout=0.0, dtype=dtype).cuda().eval()
+    B, L = 3, 80
+    seq = torch.zeros(B, L, dtype=torch.int64).cuda()
+    seq[:, 1:9] = torch.randint(2, 618, (B, 8), generator=torch.Generator().manual_seed(6)).cuda()
+    a = sample_next_plus_one(m, seq.clone(), idx=9, deterministic=True, use_graph=True)
+    b = sample_next_plus_one(m, seq.clone(), idx=9, deterministic=True, use_graph=False)
+    assert torch.equal(a, b)
+    assert int((a[:, 9:L - 1] != 0).sum()) > 0
+    # stochastic path: runs, stays in the vocabulary, leaves the last position untouched
+    c = sample_next_plus_one(m, seq.clone(), idx=9, deterministic=False, use_graph=True)
+    assert int(c.max()) < 618 and torch.equal(c[:, -1], seq[:, -1]) and torch.equal(c[:, :8], seq[:, :8])
+
+
 def test_training_loop_end_to_end(tmp_path):
     """training_loop with the reference's signature: loss decreases on a repeating batch,
     checkpoints carry the reference's keys ('optmizer', 'grad_scaler', model 'mask') and resume."""
