@@ -21,7 +21,7 @@ int mgx_attn_bwd_generic(int mode, const void* dout, const void* qkv, const void
                          const float* slopes, const void* E, void* dqkv, float* dE, float* delta, int B, int S, int H,
                          int dh, int max_seq, int dtype, hipStream_t st);
 // attn_mfma.hip
-bool mgx_attn_mfma_supported(int mode, int dh, int dtype, int S, int H);
+bool mgx_attn_mfma_supported(int mode, int dh, int dtype, int S, int H, int max_seq, bool backward);
 int mgx_attn_fwd_mfma(int mode, const void* qkv, const float* slopes, const void* E, void* out, float* lse, int B,
                       int S, int H, int dh, int max_seq, hipStream_t st);
 int mgx_attn_bwd_mfma(int mode, const void* dout, const void* qkv, const void* out, const float* lse,
@@ -37,7 +37,7 @@ extern "C" int mgx_alibi_attn_fwd(const void* qkv, const float* slopes, void* ou
     MGX_REQUIRE(qkv && slopes && out && lse, MGX_EINVAL, "mgx_alibi_attn_fwd: null pointer");
     int rc = mgx_check_attn_shape("mgx_alibi_attn_fwd", B, S, H, dh, dtype);
     if (rc) return rc;
-    if (!g_force_generic && mgx_attn_mfma_supported(0, dh, dtype, S, H))
+    if (!g_force_generic && mgx_attn_mfma_supported(0, dh, dtype, S, H, 0, false))
         return mgx_attn_fwd_mfma(0, qkv, slopes, nullptr, out, lse, B, S, H, dh, 0, (hipStream_t)stream);
     return mgx_attn_fwd_generic(0, qkv, slopes, nullptr, out, lse, B, S, H, dh, 0, dtype, (hipStream_t)stream);
 }
@@ -48,7 +48,7 @@ extern "C" int mgx_alibi_attn_bwd(const void* dout, const void* qkv, const void*
     MGX_REQUIRE(dout && qkv && out && lse && slopes && dqkv && delta, MGX_EINVAL, "mgx_alibi_attn_bwd: null pointer");
     int rc = mgx_check_attn_shape("mgx_alibi_attn_bwd", B, S, H, dh, dtype);
     if (rc) return rc;
-    if (!g_force_generic && mgx_attn_mfma_supported(0, dh, dtype, S, H))
+    if (!g_force_generic && mgx_attn_mfma_supported(0, dh, dtype, S, H, 0, true))
         return mgx_attn_bwd_mfma(0, dout, qkv, out, lse, slopes, nullptr, dqkv, nullptr, delta, B, S, H, dh, 0,
                                  (hipStream_t)stream);
     return mgx_attn_bwd_generic(0, dout, qkv, out, lse, slopes, nullptr, dqkv, nullptr, delta, B, S, H, dh, 0, dtype,
@@ -61,7 +61,7 @@ extern "C" int mgx_rel_attn_fwd(const void* qkv, const void* E, void* out, float
     int rc = mgx_check_attn_shape("mgx_rel_attn_fwd", B, S, H, dh, dtype);
     if (rc) return rc;
     MGX_REQUIRE(S <= max_seq, MGX_EINVAL, "mgx_rel_attn_fwd: S=%d exceeds max_seq=%d", S, max_seq);
-    if (!g_force_generic && mgx_attn_mfma_supported(1, dh, dtype, S, H))
+    if (!g_force_generic && mgx_attn_mfma_supported(1, dh, dtype, S, H, max_seq, false))
         return mgx_attn_fwd_mfma(1, qkv, nullptr, E, out, lse, B, S, H, dh, max_seq, (hipStream_t)stream);
     return mgx_attn_fwd_generic(1, qkv, nullptr, E, out, lse, B, S, H, dh, max_seq, dtype, (hipStream_t)stream);
 }
@@ -74,7 +74,7 @@ extern "C" int mgx_rel_attn_bwd(const void* dout, const void* qkv, const void* o
     if (rc) return rc;
     MGX_REQUIRE(S <= max_seq, MGX_EINVAL, "mgx_rel_attn_bwd: S=%d exceeds max_seq=%d", S, max_seq);
     MGX_REQUIRE(max_seq <= 65535, MGX_EUNSUPPORTED, "mgx_rel_attn_bwd: max_seq too large");
-    if (!g_force_generic && mgx_attn_mfma_supported(1, dh, dtype, S, H))
+    if (!g_force_generic && mgx_attn_mfma_supported(1, dh, dtype, S, H, max_seq, true))
         return mgx_attn_bwd_mfma(1, dout, qkv, out, lse, nullptr, E, dqkv, dE, delta, B, S, H, dh, max_seq,
                                  (hipStream_t)stream);
     return mgx_attn_bwd_generic(1, dout, qkv, out, lse, nullptr, E, dqkv, dE, delta, B, S, H, dh, max_seq, dtype,

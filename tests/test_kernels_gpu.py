@@ -153,6 +153,37 @@ def test_relative_attention(B, S, H, dh, M, dtype):
     assert gu.rel_err(dE, ref_E.grad) < tol
 
 
+@pytest.mark.parametrize("B,S,H,dh,M", [(2, 150, 2, 64, 160), (1, 600, 3, 64, 640), (2, 257, 2, 128, 264),
+                                         (1, 384, 2, 64, 384), (1, 31, 1, 64, 32), (1, 129, 2, 128, 1024)])
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_relative_attention_bf16_mfma(B, S, H, dh, M, force_generic):
+    """Skew relative attention on the MFMA path (ring skew through LDS, dE band kernel) and on the
+    generic path, against the oracle's pad/reshape skew in fp32 on the same bf16-rounded inputs."""
+    ops = _ops()
+    from musicgeneration_amd._lib import lib
+    g = torch.Generator().manual_seed(S * 3 + dh + M)
+    qkv = torch.randn(B, S, 3 * H * dh, generator=g).bfloat16()
+    E = (0.5 * torch.randn(H, M, dh, generator=g)).bfloat16()
+    dout = torch.randn(B, S, H * dh, generator=g).bfloat16()
+    ref_in = qkv.float().requires_grad_(True)
+    ref_E = E.float().requires_grad_(True)
+    ref = _ref_attn(ref_in, H, E=ref_E, max_seq=M)
+    ref.backward(dout.float())
+    lib.mgx_debug_force_generic_attention(1 if force_generic else 0)
+    try:
+        out, lse = ops.rel_attn_fwd(qkv.cuda(), E.cuda(), H)
+        dqkv, dE = ops.rel_attn_bwd(dout.cuda(), qkv.cuda(), out, lse, E.cuda(), H)
+    finally:
+        lib.mgx_debug_force_generic_attention(0)
+    assert gu.rel_err(out.float(), ref) < BF16_TOL
+    q, k, _ = (O._heads(t, H) for t in torch.split(qkv.float(), H * dh, dim=2))
+    w = (q @ k.transpose(-1, -2) + O.skew_relative_logits(q, E.float(), M)) / math.sqrt(dh) + O.causal_mask(S)
+    assert float((lse.cpu() - torch.logsumexp(w, -1)).abs().max()) < 2e-2
+    assert gu.rel_err(dqkv.float(), ref_in.grad) < BF16_TOL
+    assert gu.rel_err(dE, ref_E.grad) < BF16_TOL
+    assert float(dE[:, :M - S].abs().max()) == 0.0 if M > S else True
+
+
 @pytest.mark.parametrize("T,d", [(96, 64), (37, 96), (128, 512), (64, 1024), (20, 2048)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("with_res", [True, False])
