@@ -176,33 +176,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_mfma_kernel(const bf16_t*
 // ===========================================================================
 // backward
 // ===========================================================================
-// delta[b,h,i] = sum_d dout[b,i,h,d]*out[b,i,h,d]; one 16-byte chunk per lane, dh/8 lanes per head.
-template <int DH>
-__global__ __launch_bounds__(256) void attn_delta_mfma_kernel(const bf16_t* __restrict__ dout,
-                                                               const bf16_t* __restrict__ out,
-                                                               float* __restrict__ delta, long n_chunks, int S,
-                                                               int H) {
-    constexpr int LPH = DH / 8;
-    const long c = (long)blockIdx.x * 256 + threadIdx.x;
-    float s = 0.f;
-    if (c < n_chunks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(dout + c * 8);
-        const bf16x8 o = *reinterpret_cast<const bf16x8*>(out + c * 8);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s = fmaf((float)a[k], (float)o[k], s);
-    }
-#pragma unroll
-    for (int o = 1; o < LPH; o <<= 1) s += __shfl_xor(s, o, 64);
-    if (c < n_chunks && (c % LPH) == 0) {
-        const long bh = c / LPH;                 // (b*S + i)*H + h
-        const int h = (int)(bh % H);
-        const long bi = bh / H;
-        const int i = (int)(bi % S);
-        const long b = bi / S;
-        delta[(b * H + h) * S + i] = s;
-    }
-}
-
 // dQ: query on the lane (as the forward).  Per 32-key block:
 //   S^T = K.Q^T (+bias)   dP^T = V.dO^T (-delta)   dS^T = P^T*(dP^T)*scale   dQ^T += K^T.dS^T
 template <int DH, int NW>
@@ -495,7 +468,7 @@ bool mgx_attn_mfma_supported(int mode, int dh, int dtype, int S, int H, int max_
     if (!(dtype == MGX_BF16 && (dh == 64 || dh == 128) && (long)S * 3 * H * dh * 2 < (1L << 31))) return false;
     if (mode == 0) return true;
     // skew-relative mode: the backward reads a transposed copy of E with 16-byte loads
-    return mode == 1 && max_seq % 8 == 0 && (!backward || mgx_rel_bwd_mfma_ready());
+    return mode == 1 && max_seq % 8 == 0 && max_seq >= 32 && (!backward || mgx_rel_bwd_mfma_ready());
 }
 
 int mgx_attn_fwd_mfma(int mode, const void* qkv, const float* slopes, const void* E, void* out, float* lse, int B,

@@ -120,4 +120,31 @@ struct LaneAddr {
     }
 };
 
+// delta[b,h,i] = sum_d dout[b,i,h,d]*out[b,i,h,d]; one 16-byte chunk per lane, dh/8 lanes per head.
+template <int DH>
+__global__ __launch_bounds__(256) void attn_delta_mfma_kernel(const bf16_t* __restrict__ dout,
+                                                               const bf16_t* __restrict__ out,
+                                                               float* __restrict__ delta, long n_chunks, int S,
+                                                               int H) {
+    constexpr int LPH = DH / 8;
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    float s = 0.f;
+    if (c < n_chunks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(dout + c * 8);
+        const bf16x8 o = *reinterpret_cast<const bf16x8*>(out + c * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s = fmaf((float)a[k], (float)o[k], s);
+    }
+#pragma unroll
+    for (int o = 1; o < LPH; o <<= 1) s += __shfl_xor(s, o, 64);
+    if (c < n_chunks && (c % LPH) == 0) {
+        const long bh = c / LPH;                 // (b*S + i)*H + h
+        const int h = (int)(bh % H);
+        const long bi = bh / H;
+        const int i = (int)(bi % S);
+        const long b = bi / S;
+        delta[(b * H + h) * S + i] = s;
+    }
+}
+
 }  // namespace
