@@ -145,7 +145,7 @@ def main():
     if a.workload == "decode_unified":
         return bench_decode(a, device, rank, world)
 
-    defaults = {"train_unified": (16, 2048), "train_separated": (8, 1024), "train_relative": (2, 4096)}[a.workload]
+    defaults = {"train_unified": (16, 2048), "train_separated": (8, 1024), "train_relative": (8, 4096)}[a.workload]
     B = a.batch or defaults[0]
     S = a.seq or defaults[1]
     from musicgeneration_amd import ops

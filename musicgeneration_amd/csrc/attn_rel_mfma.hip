@@ -24,6 +24,9 @@ namespace {
 #ifndef MGX_REL_NW
 #define MGX_REL_NW 4
 #endif
+#ifndef MGX_REL_DE_NW
+#define MGX_REL_DE_NW 2          // dE kernel: 64 distances per band x 2 query-half groups = 4 waves; bands paired
+#endif
 constexpr int SKS = 68;          // ring row stride in floats (272 B: 16-byte reads of 16 consecutive lanes spread over all banks)
 
 // ---- the skew ring (query-on-lane kernels) ----------------------------------------------------
@@ -601,18 +604,18 @@ __global__ __launch_bounds__(64 * NW, (DH == 128 ? 1 : 2)) void rel_bwd_dkv_mfma
 //   S = Q.K^T, dP = dO.V^T on those key blocks -> skew to distance coordinates
 //   W = skew(S) + Q.Er^T - lse   P = exp2   dW = P*(skew(dP) - delta)*scale
 //   dEr^T[d, r] += Q^T . dW      (accumulators live in registers for the whole launch)
-template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void rel_bwd_de_mfma_kernel(
-    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
-    const float* __restrict__ delta, const bf16_t* __restrict__ E, float* __restrict__ dE, int B, int S, int H, int M,
-    float c, float scale) {
-    constexpr int NT = 64 * NW, RB = 32 * NW, TB = Img<DH>::TILE_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (Q, dO images), stats, NW skew buffers
+template <int DH, int NWD>
+__device__ __forceinline__ void rel_de_band(
+    char* smem, const int rb0, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qkv,
+    const float* __restrict__ lse, const float* __restrict__ delta, const bf16_t* __restrict__ E,
+    float* __restrict__ dE, int B, int S, int H, int M, float c, float scale) {
+    constexpr int NW = 2 * NWD, NT = 64 * NW, TB = Img<DH>::TILE_BYTES;
     float* stats = reinterpret_cast<float*>(smem + 4 * TB);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, h5 = lane >> 5;
     float* skew = stats + 4 * 64 + w * 32 * BKS;
-    const int rb0 = blockIdx.y * RB, rw0 = rb0 + 32 * w;      // small distances (longest bands) first
+    const int rw0 = rb0 + 32 * (w % NWD);
+    const int tb = w / NWD;                               // which 32-query half of every staged tile this wave takes
     const int h = blockIdx.x;
     const unsigned rs = 3u * H * DH;
     const bf16_t* Eh = E + (long)h * M * DH;
@@ -659,20 +662,18 @@ __global__ __launch_bounds__(64 * NW, 1) void rel_bwd_de_mfma_kernel(
         // key/value rows JB + l31 of the upper key block, as B operands; the lower block is the
         // previous query block's upper one
         bf16x8 ka[DH / 16], kb[DH / 16], va[DH / 16], vb[DH / 16];
-        auto load_kv = [&](int J) {
-            const int row = min(max(J + l31, 0), S - 1);
+        auto load_kv = [&](int J) {                        // rows J-32.. (lower block) and J.. (upper block)
+            const int ra = min(max(J - 32 + l31, 0), S - 1), rb = min(max(J + l31, 0), S - 1);
 #pragma unroll
             for (int ks = 0; ks < DH / 16; ++ks) {
-                kb[ks] = *reinterpret_cast<const bf16x8*>(kp + (long)row * rs + 16 * ks);
-                vb[ks] = *reinterpret_cast<const bf16x8*>(vp + (long)row * rs + 16 * ks);
+                ka[ks] = *reinterpret_cast<const bf16x8*>(kp + (long)ra * rs + 16 * ks);
+                va[ks] = *reinterpret_cast<const bf16x8*>(vp + (long)ra * rs + 16 * ks);
+                kb[ks] = *reinterpret_cast<const bf16x8*>(kp + (long)rb * rs + 16 * ks);
+                vb[ks] = *reinterpret_cast<const bf16x8*>(vp + (long)rb * rs + 16 * ks);
             }
         };
-        load_kv(0);
-#pragma unroll
-        for (int ks = 0; ks < DH / 16; ++ks) {
-            ka[ks] = kb[ks];
-            va[ks] = vb[ks];
-        }
+        // the wave's first block is the first I0 = 64 t + 32 tb >= rw0
+        load_kv(((max(rw0 - 32 * tb, 0) + 63) / 64) * 64 + 32 * tb - rw0);
         __syncthreads();                                   // previous batch element's tiles are consumed
         load_tile(t0 * 64);
         store_tile(t0 * 64, 0);
@@ -687,11 +688,10 @@ __global__ __launch_bounds__(64 * NW, 1) void rel_bwd_de_mfma_kernel(
             const float* Dn = Ls + 64;
             if (t + 1 < ntiles) store_tile(i0 + 64, buf ^ 1);
             if (t + 2 < ntiles) load_tile(i0 + 128);
-            if (i0 + 63 >= rw0 && rw0 < S) {                   // wave-uniform
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb) {
+            if (rw0 < S) {                                     // wave-uniform
+                {
                     const int JB = i0 + 32 * tb - rw0;         // key of (query block start, distance rw0)
-                    if (JB < 0) continue;
+                    if (JB < 0) goto next_tile;
                     bf16x8 af[DH / 16], gfr[DH / 16];
 #pragma unroll
                     for (int ks = 0; ks < DH / 16; ++ks) {
@@ -725,13 +725,7 @@ __global__ __launch_bounds__(64 * NW, 1) void rel_bwd_de_mfma_kernel(
                         band_put(skew, pb, 1, l31, h5);
                         band_get(skew, dp, l31, h5);
                     }
-                    // slide the key window: this block's upper keys are the next block's lower keys
-#pragma unroll
-                    for (int ks = 0; ks < DH / 16; ++ks) {
-                        ka[ks] = kb[ks];
-                        va[ks] = vb[ks];
-                    }
-                    load_kv(JB + 32);
+                    load_kv(JB + 64);                          // this wave's next block (one tile further)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 lv = *reinterpret_cast<const f32x4*>(Ls + 32 * tb + 8 * g + 4 * h5);
@@ -763,10 +757,28 @@ __global__ __launch_bounds__(64 * NW, 1) void rel_bwd_de_mfma_kernel(
                     }
                 }
             }
+        next_tile:
             __syncthreads();
         }
     }
-    if (r < M) {
+    // the two query-half groups hold partial sums of the same distances: add them in a fixed order
+    {
+        float* red = reinterpret_cast<float*>(smem) + (size_t)(w % NWD) * (DH / 32) * 16 * 64;
+        if (tb == 1) {
+#pragma unroll
+            for (int d = 0; d < DH / 32; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[(d * 16 + e) * 64 + lane] = de[d][e];
+        }
+        __syncthreads();
+        if (tb == 0) {
+#pragma unroll
+            for (int d = 0; d < DH / 32; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) de[d][e] += red[(d * 16 + e) * 64 + lane];
+        }
+    }
+    if (tb == 0 && r < M) {
         float* op = dE + ((long)h * M + (M - 1 - r)) * DH;
 #pragma unroll
         for (int d = 0; d < DH / 32; ++d)
@@ -777,6 +789,22 @@ __global__ __launch_bounds__(64 * NW, 1) void rel_bwd_de_mfma_kernel(
                 for (int k = 0; k < 4; ++k) v[k] = de[d][4 * g + k];
                 *reinterpret_cast<f32x4*>(op + 32 * d + 8 * g + 4 * h5) = v;
             }
+    }
+}
+
+// Band y and band N-1-y have complementary lengths (S - r queries each): one workgroup takes both,
+// so every workgroup of the launch carries the same amount of work.
+template <int DH, int NWD>
+__global__ __launch_bounds__(128 * NWD, 1) void rel_bwd_de_mfma_kernel(
+    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
+    const float* __restrict__ delta, const bf16_t* __restrict__ E, float* __restrict__ dE, int B, int S, int H, int M,
+    int nbands, float c, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (Q, dO images), stats, NW skew buffers
+    const int y = blockIdx.y, y2 = nbands - 1 - y;
+    rel_de_band<DH, NWD>(smem, y * 32 * NWD, dout, qkv, lse, delta, E, dE, B, S, H, M, c, scale);
+    if (y2 > y) {
+        __syncthreads();
+        rel_de_band<DH, NWD>(smem, y2 * 32 * NWD, dout, qkv, lse, delta, E, dE, B, S, H, M, c, scale);
     }
 }
 
@@ -839,10 +867,13 @@ int launch_rel_bwd(const void* dout, const void* qkv, const void* out, const flo
                        (const bf16_t*)dout, (const bf16_t*)qkv, lse, delta, (const bf16_t*)E, (const bf16_t*)ErT,
                        (bf16_t*)dqkv, S, H, M, Mp, c, scale);
     MGX_CHECK_LAUNCH("rel_bwd_dq_mfma");
-    dim3 gride(H, (M + 32 * NW - 1) / (32 * NW));
-    allow_smem(rel_bwd_de_mfma_kernel<DH, NW>, band_smem);
-    hipLaunchKernelGGL((rel_bwd_de_mfma_kernel<DH, NW>), gride, dim3(64 * NW), band_smem, st, (const bf16_t*)dout,
-                       (const bf16_t*)qkv, lse, delta, (const bf16_t*)E, dE, B, S, H, M, c, scale);
+    constexpr int NWE = MGX_REL_DE_NW;
+    const int nbands = (M + 32 * NWE - 1) / (32 * NWE);
+    const size_t de_smem = (size_t)4 * Img<DH>::TILE_BYTES + 4 * 64 * sizeof(float) + (size_t)2 * NWE * 32 * BKS * sizeof(float);
+    dim3 gride(H, (nbands + 1) / 2);
+    allow_smem(rel_bwd_de_mfma_kernel<DH, NWE>, de_smem);
+    hipLaunchKernelGGL((rel_bwd_de_mfma_kernel<DH, NWE>), gride, dim3(128 * NWE), de_smem, st, (const bf16_t*)dout,
+                       (const bf16_t*)qkv, lse, delta, (const bf16_t*)E, dE, B, S, H, M, nbands, c, scale);
     MGX_CHECK_LAUNCH("rel_bwd_de_mfma");
     return MGX_OK;
 }
