@@ -610,7 +610,13 @@ __device__ __forceinline__ void rel_de_band(
     const float* __restrict__ lse, const float* __restrict__ delta, const bf16_t* __restrict__ E,
     float* __restrict__ dE, int B, int S, int H, int M, float c, float scale) {
     constexpr int NW = 2 * NWD, NT = 64 * NW, TB = Img<DH>::TILE_BYTES;
-    float* stats = reinterpret_cast<float*>(smem + 4 * TB);
+    static_assert(NWD % 2 == 0, "a band must cover whole 64-key tiles");
+    // Keys/values of the band: staged through a 3-slot LDS ring of 64-key tiles (tiles T-1, T in use,
+    // T+1 being filled) when it fits (dh 64); at dh 128 the ring would exceed 160 KB and each wave
+    // fetches its two 32-key operand blocks straight from global memory instead.
+    constexpr bool KVL = DH == 64;
+    char* kvring = smem + 4 * TB;
+    float* stats = reinterpret_cast<float*>(smem + (KVL ? 10 : 4) * TB);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, h5 = lane >> 5;
     float* skew = stats + 4 * 64 + w * 32 * BKS;
@@ -635,16 +641,21 @@ __device__ __forceinline__ void rel_de_band(
     const int ntiles = (S + 63) / 64;
     for (int b = 0; b < B && rb0 < S; ++b) {
         const bf16_t* base = qkv + (long)b * S * rs + (long)h * DH;
-        const bf16_t* kp = base + (long)H * DH + 8 * h5;
-        const bf16_t* vp = base + 2L * H * DH + 8 * h5;
+        const bf16_t* kp = base + (long)H * DH;
+        const bf16_t* vp = base + 2L * H * DH;
         const bf16_t* gp = dout + (long)b * S * H * DH + (long)h * DH;
         const float* lse_bh = lse + ((long)b * H + h) * S;
         const float* delta_bh = delta + ((long)b * H + h) * S;
-        TileRegs<DH, NT> qr, gr;
+        TileRegs<DH, NT> qr, gr, kr, vr;
         float r_lse = 0.f, r_delta = 0.f;
+        // query tile at i0 travels with key tile at i0 - rb0 (the keys at distance rb0.. below it)
         auto load_tile = [&](int i0) {
             tile_load<DH, NT>(qr, base, rs, i0, S, tid);
             tile_load<DH, NT>(gr, gp, (unsigned)(H * DH), i0, S, tid);
+            if (KVL) {
+                tile_load<DH, NT>(kr, kp, rs, i0 - rb0, S, tid);
+                tile_load<DH, NT>(vr, vp, rs, i0 - rb0, S, tid);
+            }
             if (tid < 64 && i0 + tid < S) {
                 r_lse = lse_bh[i0 + tid];
                 r_delta = delta_bh[i0 + tid];
@@ -653,27 +664,30 @@ __device__ __forceinline__ void rel_de_band(
         auto store_tile = [&](int i0, int buf) {
             tile_store<DH, NT>(qr, smem + buf * 2 * TB, tid);
             tile_store<DH, NT>(gr, smem + buf * 2 * TB + TB, tid);
+            if (KVL) {
+                char* slot = kvring + (((i0 - rb0) >> 6) % 3) * 2 * TB;
+                tile_store<DH, NT>(kr, slot, tid);
+                tile_store<DH, NT>(vr, slot + TB, tid);
+            }
             if (tid < 64) {
                 const bool ok = i0 + tid < S;
                 stats[buf * 128 + tid] = ok ? -(r_lse * LOG2E * inv_c) : -INFINITY;
                 stats[buf * 128 + 64 + tid] = ok ? -r_delta : 0.f;
             }
         };
-        // key/value rows JB + l31 of the upper key block, as B operands; the lower block is the
-        // previous query block's upper one
-        bf16x8 ka[DH / 16], kb[DH / 16], va[DH / 16], vb[DH / 16];
+        bf16x8 ka[DH / 16], kb[DH / 16], va[DH / 16], vb[DH / 16];      // !KVL: operand blocks from global
         auto load_kv = [&](int J) {                        // rows J-32.. (lower block) and J.. (upper block)
             const int ra = min(max(J - 32 + l31, 0), S - 1), rb = min(max(J + l31, 0), S - 1);
 #pragma unroll
             for (int ks = 0; ks < DH / 16; ++ks) {
-                ka[ks] = *reinterpret_cast<const bf16x8*>(kp + (long)ra * rs + 16 * ks);
-                va[ks] = *reinterpret_cast<const bf16x8*>(vp + (long)ra * rs + 16 * ks);
-                kb[ks] = *reinterpret_cast<const bf16x8*>(kp + (long)rb * rs + 16 * ks);
-                vb[ks] = *reinterpret_cast<const bf16x8*>(vp + (long)rb * rs + 16 * ks);
+                ka[ks] = *reinterpret_cast<const bf16x8*>(kp + (long)ra * rs + 16 * ks + 8 * h5);
+                va[ks] = *reinterpret_cast<const bf16x8*>(vp + (long)ra * rs + 16 * ks + 8 * h5);
+                kb[ks] = *reinterpret_cast<const bf16x8*>(kp + (long)rb * rs + 16 * ks + 8 * h5);
+                vb[ks] = *reinterpret_cast<const bf16x8*>(vp + (long)rb * rs + 16 * ks + 8 * h5);
             }
         };
         // the wave's first block is the first I0 = 64 t + 32 tb >= rw0
-        load_kv(((max(rw0 - 32 * tb, 0) + 63) / 64) * 64 + 32 * tb - rw0);
+        if (!KVL) load_kv(((max(rw0 - 32 * tb, 0) + 63) / 64) * 64 + 32 * tb - rw0);
         __syncthreads();                                   // previous batch element's tiles are consumed
         load_tile(t0 * 64);
         store_tile(t0 * 64, 0);
@@ -698,6 +712,12 @@ __device__ __forceinline__ void rel_de_band(
                         af[ks] = lds_read16(Qs + la.row_read(tb, ks));
                         gfr[ks] = lds_read16(Gs + la.row_read(tb, ks));
                     }
+                    // upper key block [JB, JB+32) and lower [JB-32, JB): halves of ring tiles
+                    const char* Kb = kvring + ((JB >> 6) % 3) * 2 * TB;
+                    const int hb = (JB >> 5) & 1;
+                    const int JA = max(JB - 32, 0);
+                    const char* Ka = kvring + ((JA >> 6) % 3) * 2 * TB;
+                    const int ha = (JA >> 5) & 1;
                     f32x16 sc, dp;
                     {
                         f32x16 sa, sb;
@@ -705,8 +725,8 @@ __device__ __forceinline__ void rel_de_band(
                         for (int e = 0; e < 16; ++e) sa[e] = sb[e] = 0.f;
 #pragma unroll
                         for (int ks = 0; ks < DH / 16; ++ks) {
-                            sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], kb[ks], sb, 0, 0, 0);
-                            if (JB > 0) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], ka[ks], sa, 0, 0, 0);
+                            sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], KVL ? lds_read16(Kb + la.row_read(hb, ks)) : kb[ks], sb, 0, 0, 0);
+                            if (JB > 0) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], KVL ? lds_read16(Ka + la.row_read(ha, ks)) : ka[ks], sa, 0, 0, 0);
                         }
                         band_put(skew, sa, 0, l31, h5);
                         band_put(skew, sb, 1, l31, h5);
@@ -718,14 +738,14 @@ __device__ __forceinline__ void rel_de_band(
                         for (int e = 0; e < 16; ++e) pa[e] = pb[e] = 0.f;
 #pragma unroll
                         for (int ks = 0; ks < DH / 16; ++ks) {
-                            pb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[ks], vb[ks], pb, 0, 0, 0);
-                            if (JB > 0) pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[ks], va[ks], pa, 0, 0, 0);
+                            pb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[ks], KVL ? lds_read16(Kb + TB + la.row_read(hb, ks)) : vb[ks], pb, 0, 0, 0);
+                            if (JB > 0) pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[ks], KVL ? lds_read16(Ka + TB + la.row_read(ha, ks)) : va[ks], pa, 0, 0, 0);
                         }
                         band_put(skew, pa, 0, l31, h5);
                         band_put(skew, pb, 1, l31, h5);
                         band_get(skew, dp, l31, h5);
                     }
-                    load_kv(JB + 64);                          // this wave's next block (one tile further)
+                    if (!KVL) load_kv(JB + 64);                // this wave's next block (one tile further)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 lv = *reinterpret_cast<const f32x4*>(Ls + 32 * tb + 8 * g + 4 * h5);
@@ -869,7 +889,7 @@ int launch_rel_bwd(const void* dout, const void* qkv, const void* out, const flo
     MGX_CHECK_LAUNCH("rel_bwd_dq_mfma");
     constexpr int NWE = MGX_REL_DE_NW;
     const int nbands = (M + 32 * NWE - 1) / (32 * NWE);
-    const size_t de_smem = (size_t)4 * Img<DH>::TILE_BYTES + 4 * 64 * sizeof(float) + (size_t)2 * NWE * 32 * BKS * sizeof(float);
+    const size_t de_smem = (size_t)(DH == 64 ? 10 : 4) * Img<DH>::TILE_BYTES + 4 * 64 * sizeof(float) + (size_t)2 * NWE * 32 * BKS * sizeof(float);
     dim3 gride(H, (nbands + 1) / 2);
     allow_smem(rel_bwd_de_mfma_kernel<DH, NWE>, de_smem);
     hipLaunchKernelGGL((rel_bwd_de_mfma_kernel<DH, NWE>), gride, dim3(128 * NWE), de_smem, st, (const bf16_t*)dout,
