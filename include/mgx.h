@@ -150,6 +150,14 @@ int mgx_decode_attn_at(const void* q, const void* kcache, const void* vcache, co
 int mgx_kv_append_at(const void* qkv, void* kcache, void* vcache,
                      int B, int R, int H, int dh, int Lmax, const int* pos0_dev, int dtype, void* stream);
 
+/* One call per layer and sampling step: append the R new K/V rows of qkv [B,R,3,H,dh] to the caches at
+ * pos0.. AND attend the R query rows of the same qkv against keys 0..pos0+r (mgx_kv_append +
+ * mgx_decode_attn without the intermediate q copy).  pos0_dev != NULL: the position is read from
+ * device memory (HIP-graph replay), pos0 is ignored.  bf16 with dh in {64,128} only
+ * (MGX_EUNSUPPORTED otherwise: use the two calls above). */
+int mgx_decode_step_attn(const void* qkv, void* kcache, void* vcache, const float* slopes, void* out,
+                         int B, int R, int H, int dh, int Lmax, int pos0, const int* pos0_dev, int dtype, void* stream);
+
 /* ---- fused AdamW ---------------------------------------------------------------------
  * Replaces torch.optim.AdamW.step (build_everything_unified.py:42) for one flat
  * chunk: decoupled weight decay, bias-corrected moments; also refreshes the bf16

@@ -180,14 +180,13 @@ __device__ __forceinline__ float dpp_add(float v, const int ctrl_tag) {
 #ifndef MGX_DEC_U
 #define MGX_DEC_U 4
 #endif
-#ifndef MGX_DEC_PF
-#define MGX_DEC_PF 0
-#endif
 template <int DH, int NW, int R>
 __global__ __launch_bounds__(NW * 64, 4) void decode_attn_bf16_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
     const float* __restrict__ slopes, bf16_t* __restrict__ out, int H, int Lmax, int pos0_host,
-    const int* __restrict__ pos_dev, float scale_log2e) {
+    const int* __restrict__ pos_dev, float scale_log2e, const bf16_t* __restrict__ qkv_new) {
+    // qkv_new != NULL (fused step): q, and the K/V rows of positions pos0.., come straight from the
+    // projection output [B,R,3,H,DH]; this workgroup also files those K/V rows into the caches.
     constexpr int LPR = DH / 8;          // lanes per key row: 16 (dh 128) or 8 (dh 64)
     constexpr int RPL = 64 / LPR;        // key rows per wave-load
     constexpr int U = MGX_DEC_U;         // wave-loads per chunk
@@ -204,7 +203,8 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attn_bf16_kernel(
     bf16x2 qp[R][4];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const bf16x8 t = *reinterpret_cast<const bf16x8*>(q + (((long)b * R + r) * H + h) * DH + ch * 8);
+        const bf16_t* qsrc = qkv_new ? qkv_new + (((long)b * R + r) * 3 * H + h) * DH : q + (((long)b * R + r) * H + h) * DH;
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(qsrc + ch * 8);
 #pragma unroll
         for (int k = 0; k < 4; ++k) qp[r][k] = bf16x2{t[2 * k], t[2 * k + 1]};
     }
@@ -222,25 +222,47 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attn_bf16_kernel(
     const int nkeys = pos0 + R;
     const int last = nkeys - 1;
     constexpr int STEP = NW * U * RPL;
-
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    u32x4 kcur[U], vcur[U], knxt[U], vnxt[U];
-    int j0 = w * U * RPL;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int j = min(j0 + u * RPL + sub, last);
-        kcur[u] = *reinterpret_cast<const u32x4*>(kb + (long)j * DH);
-        vcur[u] = *reinterpret_cast<const u32x4*>(vb + (long)j * DH);
-    }
-    for (; j0 < nkeys; j0 += STEP) {
-        if (MGX_DEC_PF && j0 + STEP < nkeys) {             // wave-uniform
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = min(j0 + STEP + u * RPL + sub, last);
-                knxt[u] = *reinterpret_cast<const u32x4*>(kb + (long)j * DH);
-                vnxt[u] = *reinterpret_cast<const u32x4*>(vb + (long)j * DH);
-            }
+
+    // Fused step: keys 0..pos0-1 come from the cache, the R new keys straight from qkv_new (wave 0 takes
+    // them as one extra chunk after its share of the cache) and are filed into the cache on the way.
+    const bf16_t* nk = qkv_new ? qkv_new + (((long)b * R * 3 + 1) * H + h) * DH + ch * 8 : nullptr;   // K of new row 0
+    const long nstep = 3L * H * DH;                      // to the next new row; V sits H*DH after K
+    if (nk && w == 0) {
+        for (int e = lane; e < R * LPR; e += 64) {
+            const int r = e / LPR, c = e % LPR;
+            const bf16_t* src = qkv_new + (((long)b * R + r) * 3 + 1) * H * DH + (long)h * DH + c * 8;
+            const long dst = (((long)b * H + h) * Lmax + pos0 + r) * DH + c * 8;
+            *reinterpret_cast<u32x4*>(const_cast<bf16_t*>(kc) + dst) = *reinterpret_cast<const u32x4*>(src);
+            *reinterpret_cast<u32x4*>(const_cast<bf16_t*>(vc) + dst) = *reinterpret_cast<const u32x4*>(src + (long)H * DH);
         }
+    }
+    const int nkc = nk ? pos0 : nkeys;                   // keys served by the cache
+    const int lastc = max(nkc - 1, 0);
+    u32x4 kcur[U], vcur[U];
+    auto load_cache = [&](int jb) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = min(jb + u * RPL + sub, lastc);
+            kcur[u] = *reinterpret_cast<const u32x4*>(kb + (long)j * DH);
+            vcur[u] = *reinterpret_cast<const u32x4*>(vb + (long)j * DH);
+        }
+    };
+    auto load_new = [&]() {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = min(u * RPL + sub, R - 1);
+            kcur[u] = *reinterpret_cast<const u32x4*>(nk + r * nstep);
+            vcur[u] = *reinterpret_cast<const u32x4*>(nk + r * nstep + (long)H * DH);
+        }
+    };
+    int j0 = w * U * RPL;
+    int lim = nkc - 1;                                   // keys j <= lim are real in the current pass
+    bool tail = false, more = true;                      // wave-uniform
+    if (j0 < nkc) load_cache(j0);
+    else if (nk && w == 0) { load_new(); j0 = pos0; lim = last; tail = true; }
+    else more = false;
+    while (more) {
         float s[R][U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -260,7 +282,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attn_bf16_kernel(
                     if (LPR == 16) a = dpp_add(a, 3);
                     const int i = pos0 + r;
                     a = fmaf(a, scale_log2e, slope2 * (float)(j - i));
-                    s[r][u] = (j > i || j > last) ? NEG : a;   // causal, and rows clamped past the end
+                    s[r][u] = (j > i || j > lim) ? NEG : a;   // causal, and rows clamped past the end
                 }
             }
         }
@@ -295,20 +317,11 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attn_bf16_kernel(
                 }
             }
         }
-        if (MGX_DEC_PF) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                kcur[u] = knxt[u];
-                vcur[u] = vnxt[u];
-            }
-        } else if (j0 + STEP < nkeys) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = min(j0 + STEP + u * RPL + sub, last);
-                kcur[u] = *reinterpret_cast<const u32x4*>(kb + (long)j * DH);
-                vcur[u] = *reinterpret_cast<const u32x4*>(vb + (long)j * DH);
-            }
-        }
+        if (tail) break;
+        j0 += STEP;
+        if (j0 < nkc) load_cache(j0);
+        else if (nk && w == 0) { load_new(); j0 = pos0; lim = last; tail = true; }
+        else more = false;
     }
     // merge the RPL lane groups of this wave (base-2 domain)
 #pragma unroll
@@ -390,8 +403,11 @@ __global__ void kv_append_kernel(const T* __restrict__ qkv, T* __restrict__ kc, 
 namespace {
 
 int decode_attn_impl(const void* q, const void* kcache, const void* vcache, const float* slopes, void* out, int B, int R,
-                     int H, int dh, int Lmax, int pos0, const int* pos_dev, int dtype, void* stream) {
-    MGX_REQUIRE(q && kcache && vcache && out, MGX_EINVAL, "mgx_decode_attn: null pointer");
+                     int H, int dh, int Lmax, int pos0, const int* pos_dev, int dtype, void* stream,
+                     const void* qkv_new = nullptr) {
+    MGX_REQUIRE((q || qkv_new) && kcache && vcache && out, MGX_EINVAL, "mgx_decode_attn: null pointer");
+    MGX_REQUIRE(!qkv_new || (dtype == MGX_BF16 && (dh == 64 || dh == 128)), MGX_EUNSUPPORTED,
+                "mgx_decode_step_attn: fused step needs bf16 and head dim 64 or 128 (got dtype %d, dh %d)", dtype, dh);
     MGX_REQUIRE(B > 0 && H > 0 && dh > 0 && R >= 1 && R <= MAXR, MGX_EINVAL, "mgx_decode_attn: B=%d R=%d H=%d dh=%d", B,
                 R, H, dh);
     MGX_REQUIRE(dtype == MGX_F32 || dtype == MGX_BF16, MGX_EINVAL, "mgx_decode_attn: bad dtype %d", dtype);
@@ -415,7 +431,7 @@ int decode_attn_impl(const void* q, const void* kcache, const void* vcache, cons
 #define MGX_DECODE_LAUNCH(DH_, NW_, R_)                                                                             \
     hipLaunchKernelGGL((decode_attn_bf16_kernel<DH_, NW_, R_>), grid, dim3(NW_ * 64), smem, st, (const bf16_t*)q,    \
                        (const bf16_t*)kcache, (const bf16_t*)vcache, slopes, (bf16_t*)out, H, Lmax, pos0, pos_dev,   \
-                       sl2)
+                       sl2, (const bf16_t*)qkv_new)
 #define MGX_DECODE_R(DH_, NW_)                      \
     switch (R) {                                    \
         case 1: MGX_DECODE_LAUNCH(DH_, NW_, 1); break; \
@@ -476,6 +492,13 @@ extern "C" int mgx_decode_attn_at(const void* q, const void* kcache, const void*
                                   int B, int R, int H, int dh, int Lmax, const int* pos0_dev, int dtype, void* stream) {
     MGX_REQUIRE(pos0_dev, MGX_EINVAL, "mgx_decode_attn_at: null position pointer");
     return decode_attn_impl(q, kcache, vcache, slopes, out, B, R, H, dh, Lmax, 0, pos0_dev, dtype, stream);
+}
+
+extern "C" int mgx_decode_step_attn(const void* qkv, void* kcache, void* vcache, const float* slopes, void* out, int B,
+                                    int R, int H, int dh, int Lmax, int pos0, const int* pos0_dev, int dtype,
+                                    void* stream) {
+    MGX_REQUIRE(qkv, MGX_EINVAL, "mgx_decode_step_attn: null pointer");
+    return decode_attn_impl(nullptr, kcache, vcache, slopes, out, B, R, H, dh, Lmax, pos0, pos0_dev, dtype, stream, qkv);
 }
 
 extern "C" int mgx_kv_append(const void* qkv, void* kcache, void* vcache, int B, int R, int H, int dh, int Lmax,

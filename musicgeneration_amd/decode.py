@@ -70,12 +70,15 @@ class KVCacheDecoder:
             wqkv, bqkv, wp, bp, w1, w2, b2 = W.wqkv, W.bqkv, W.wp, W.bp, W.w1, W.w2, W.b2
             x2 = h.reshape(T, d)
             qkv = torch.addmm(bqkv, x2, wqkv).view(B, R, 3 * d)
-            ops.kv_append(qkv, kc, vc, pos0)
-            if R <= 4:
-                q = qkv[:, :, :d].contiguous()
-                a = ops.decode_attn(q, kc, vc, layer.attn.slopes, pos0)
+            if R <= 4 and ops.decode_step_attn_supported(dt, d // layer.heads):
+                a = ops.decode_step_attn(qkv, kc, vc, layer.attn.slopes, pos0)      # append + attend, one launch
             else:
-                a, _ = ops.alibi_attn_fwd(qkv, layer.attn.slopes, layer.heads)
+                ops.kv_append(qkv, kc, vc, pos0)
+                if R <= 4:
+                    q = qkv[:, :, :d].contiguous()
+                    a = ops.decode_attn(q, kc, vc, layer.attn.slopes, pos0)
+                else:
+                    a, _ = ops.alibi_attn_fwd(qkv, layer.attn.slopes, layer.heads)
             pr = torch.addmm(bp, a.view(T, d), wp)
             h1, _, _, _ = ops.ln_residual_fwd(pr, x2, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps, save=False)
             u = torch.mm(h1, w1.t())

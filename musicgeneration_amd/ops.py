@@ -494,6 +494,30 @@ def decode_attn(q, kcache, vcache, slopes, pos0):
     return out
 
 
+def decode_step_attn_supported(dtype, dh: int) -> bool:
+    return dtype == torch.bfloat16 and dh in (64, 128)
+
+
+def decode_step_attn(qkv, kcache, vcache, slopes, pos0):
+    """kv_append + decode_attn in one launch: qkv [B,R,3*d] (R <= 4) -> out [B,R,d]; caches updated at pos0.."""
+    _need(qkv, "qkv", torch.bfloat16)
+    _need(kcache, "kcache", qkv.dtype)
+    _need(vcache, "vcache", qkv.dtype)
+    B, R, d3 = qkv.shape
+    Bc, H, Lmax, dh = kcache.shape
+    if Bc != B or 3 * H * dh != d3 or vcache.shape != kcache.shape:
+        raise ValueError("decode_step_attn shape mismatch")
+    out = torch.empty(B, R, H * dh, dtype=qkv.dtype, device=qkv.device)
+    if isinstance(pos0, torch.Tensor):
+        check(lib.mgx_decode_step_attn(_p(qkv), _p(kcache), _p(vcache), _p(slopes), _p(out), B, R, H, dh, Lmax, 0,
+                                       _dev_pos(pos0, qkv), _dt(qkv), _stream()), "mgx_decode_step_attn")
+        return out
+    with _timed("decode_attn"):
+        check(lib.mgx_decode_step_attn(_p(qkv), _p(kcache), _p(vcache), _p(slopes), _p(out), B, R, H, dh, Lmax, pos0,
+                                       None, _dt(qkv), _stream()), "mgx_decode_step_attn")
+    return out
+
+
 # ---------------------------------------------------------------------------
 # optimizer
 # ---------------------------------------------------------------------------

@@ -362,6 +362,17 @@ def test_decode_attention_streaming_bf16(B, H, dh, R, pos0):
     out = ops.decode_attn(qn, kc, vc, slopes, pos0)
     out_dev = ops.decode_attn(qn, kc, vc, slopes, pos_dev)
     assert torch.equal(out, out_dev)
+    # fused step (append + attend in one launch) vs the two separate calls: same caches; the outputs agree to
+    # bf16 rounding (the new keys are folded in by another wave, so fp32 sums associate differently)
+    kc2, vc2 = torch.zeros_like(kc), torch.zeros_like(vc)
+    if pos0 > 0:
+        ops.kv_append(qkv[:, :pos0].contiguous(), kc2, vc2, 0)
+    out_f = ops.decode_step_attn(qkv[:, pos0:].contiguous(), kc2, vc2, slopes, pos0)
+    assert torch.equal(kc2, kc) and torch.equal(vc2, vc)
+    assert gu.rel_err(out_f.float(), out.float()) < 1e-2 and gu.rel_err(out_f.float(), ref) < BF16_TOL
+    kc2[:, :, pos0:] = 0
+    out_fd = ops.decode_step_attn(qkv[:, pos0:].contiguous(), kc2, vc2, slopes, pos_dev)
+    assert torch.equal(out_fd, out_f) and torch.equal(kc2, kc)
     assert gu.rel_err(out.float(), ref) < BF16_TOL
     assert float((out.float() - ref).abs().max()) < 0.03 * float(ref.abs().max())
 
