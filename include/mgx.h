@@ -88,11 +88,14 @@ int mgx_ln_residual_fwd(const void* a, const void* res, const float* gamma, cons
  * residual-branch add of the backward).  dz [T,d] is the gradient wrt the
  * pre-norm sum (= gradient of `res`); da [T,d] (may alias dz when p_drop==0, or
  * be NULL) is dz with the dropout mask re-applied.  dgamma/dbeta [d] fp32 are
- * overwritten; partial [nblk_max*2*d] fp32 scratch, nblk_max = mgx_ln_bwd_partial_rows(). */
+ * overwritten.  dsum [d] fp32 (may be NULL) receives the column sums of da (of dz when there is
+ * no dropout): the bias gradient of the projection that produced the branch (c_proj.b / linear2.bias,
+ * alibi_unified.py:88,92), so no separate reduction pass over da is needed.
+ * partial [nblk_max*3*d] fp32 scratch, nblk_max = mgx_ln_bwd_partial_rows(). */
 int mgx_ln_bwd_partial_rows(void);
 int mgx_ln_residual_bwd(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
-                        const float* gamma, void* dz, void* da, float* dgamma, float* dbeta, float* partial,
-                        long T, int d, float p_drop, unsigned long long seed, int dtype, void* stream);
+                        const float* gamma, void* dz, void* da, float* dgamma, float* dbeta, float* dsum,
+                        float* partial, long T, int d, float p_drop, unsigned long long seed, int dtype, void* stream);
 
 /* ---- bias + activation (+ dropout) ------------------------------------------------
  * Replaces `drop(activation(linear1(x)))`'s elementwise tail (alibi_unified.py:90-91):

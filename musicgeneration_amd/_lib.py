@@ -27,7 +27,7 @@ PROTOTYPES = {
     "mgx_rel_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mgx_ln_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _f, _u64, _i, _vp]),
     "mgx_ln_bwd_partial_rows": (_i, []),
-    "mgx_ln_residual_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _u64, _i, _vp]),
+    "mgx_ln_residual_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _u64, _i, _vp]),
     "mgx_bias_act_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _f, _u64, _i, _vp]),
     "mgx_bias_act_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _f, _u64, _i, _vp]),
     "mgx_xent_sums_len": (_i, []),

@@ -126,17 +126,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                       T* __restrict__ dz, T* __restrict__ da,
                                                       float* __restrict__ partial, long T_rows, int d, float p_drop,
-                                                      unsigned long long seed) {
+                                                      unsigned long long seed, int want_dsum) {
     constexpr int N = Vec<T>::N;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][2][d]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][d], one quantity at a time
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned thr16 = mgx_drop_thr16(p_drop);
     const float keep_scale = mgx_keep_scale(thr16);
-    float g_acc[NV][N], b_acc[NV][N];
+    float g_acc[NV][N], b_acc[NV][N], a_acc[NV][N];   // dgamma, dbeta, column sum of da (the bias gradient of the branch)
 #pragma unroll
     for (int c = 0; c < NV; ++c)
 #pragma unroll
-        for (int k = 0; k < N; ++k) g_acc[c][k] = b_acc[c][k] = 0.f;
+        for (int k = 0; k < N; ++k) g_acc[c][k] = b_acc[c][k] = a_acc[c][k] = 0.f;
 
     for (long row = (long)blockIdx.x * 4 + w; row < T_rows; row += (long)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
@@ -188,34 +188,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                     }
                     store_vec<T, N>(da + row * d + col, o);
                 }
+                if (want_dsum) {
+#pragma unroll
+                    for (int k = 0; k < N; ++k) a_acc[c][k] += o[k];
+                }
             }
         }
     }
-    // block reduction of the 4 waves' column partials
-    float* sg = smem + (size_t)w * 2 * d;
-    float* sb = sg + d;
+    // block reduction of the 4 waves' column partials, one quantity at a time through [4][d] floats
+    const int nq = want_dsum ? 3 : 2;
+    float* out = partial + (size_t)blockIdx.x * nq * d;
+    float* mine = smem + (size_t)w * d;
+    for (int q = 0; q < nq; ++q) {
 #pragma unroll
-    for (int c = 0; c < NV; ++c) {
-        const int col = (c * 64 + lane) * N;
-        if (col < d) {
+        for (int c = 0; c < NV; ++c) {
+            const int col = (c * 64 + lane) * N;
+            if (col < d) {
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
-                sg[col + k] = g_acc[c][k];
-                sb[col + k] = b_acc[c][k];
+                for (int k = 0; k < N; ++k) mine[col + k] = q == 0 ? g_acc[c][k] : (q == 1 ? b_acc[c][k] : a_acc[c][k]);
             }
         }
+        __syncthreads();
+        for (int e = threadIdx.x; e < d; e += 256) out[q * d + e] = smem[e] + smem[d + e] + smem[2 * d + e] + smem[3 * d + e];
+        __syncthreads();
     }
-    __syncthreads();
-    float* out = partial + (size_t)blockIdx.x * 2 * d;
-    for (int e = threadIdx.x; e < 2 * d; e += 256)
-        out[e] = smem[e] + smem[2 * d + e] + smem[4 * d + e] + smem[6 * d + e];
 }
 
-// out0[c] = sum_r partial[r][0][c]; out1[c] = sum_r partial[r][1][c]   (nseg = 1 or 2)
+// out_q[c] = sum_r partial[r][q][c] for q < nseg (1..3)
 // Block = 64 columns x 16 row slices (fixed summation order -> deterministic).
 __global__ __launch_bounds__(1024) void column_reduce_kernel(const float* __restrict__ partial,
                                                               float* __restrict__ out0, float* __restrict__ out1,
-                                                              int nblk, int d, int nseg) {
+                                                              float* __restrict__ out2, int nblk, int d, int nseg) {
     __shared__ float sh[16][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -236,7 +239,8 @@ __global__ __launch_bounds__(1024) void column_reduce_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += sh[k][lane];
         if (c < d) out0[c] = s;
-        else out1[c - d] = s;
+        else if (c < 2 * d) out1[c - d] = s;
+        else out2[c - 2 * d] = s;
     }
 }
 
@@ -321,6 +325,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
         float acc[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) acc[k] = 0.f;
+#pragma unroll 4
         for (long row = blockIdx.x; row < T_rows; row += gridDim.x) {
             const long e = row * n + col;
             float g[N], x[N];
@@ -390,24 +395,25 @@ int ln_fwd_launch(const void* a, const void* res, const float* gamma, const floa
 
 template <typename T>
 int ln_bwd_launch(const void* dy, const void* dy2, const void* z, const float* mean, const float* rstd,
-                  const float* gamma, void* dz, void* da, float* dgamma, float* dbeta, float* partial, long T_rows,
-                  int d, float p, unsigned long long seed, hipStream_t st) {
+                  const float* gamma, void* dz, void* da, float* dgamma, float* dbeta, float* dsum, float* partial,
+                  long T_rows, int d, float p, unsigned long long seed, hipStream_t st) {
     constexpr int N = Vec<T>::N;
     const int nv = (d + 64 * N - 1) / (64 * N);
     const int nblk = (int)((T_rows + 3) / 4 < PARTIAL_ROWS ? (T_rows + 3) / 4 : PARTIAL_ROWS);
-    const size_t smem = (size_t)8 * d * sizeof(float);
+    const size_t smem = (size_t)4 * d * sizeof(float);
+    const int nq = dsum ? 3 : 2;
     dim3 grid(nblk), block(256);
 #define LN_BWD_CASE(NVV)                                                                                          \
     hipLaunchKernelGGL((ln_bwd_kernel<T, NVV>), grid, block, smem, st, (const T*)dy, (const T*)dy2, (const T*)z, \
-                       mean, rstd, gamma, (T*)dz, (T*)da, partial, T_rows, d, p, seed)
+                       mean, rstd, gamma, (T*)dz, (T*)da, partial, T_rows, d, p, seed, dsum ? 1 : 0)
     if (nv <= 1) LN_BWD_CASE(1);
     else if (nv <= 2) LN_BWD_CASE(2);
     else if (nv <= 4) LN_BWD_CASE(4);
     else LN_BWD_CASE(8);
 #undef LN_BWD_CASE
     MGX_CHECK_LAUNCH("ln_bwd");
-    hipLaunchKernelGGL(column_reduce_kernel, dim3((2 * d + 63) / 64), dim3(1024), 0, st, partial, dgamma, dbeta, nblk,
-                       d, 2);
+    hipLaunchKernelGGL(column_reduce_kernel, dim3((nq * d + 63) / 64), dim3(1024), 0, st, partial, dgamma, dbeta, dsum,
+                       nblk, d, nq);
     MGX_CHECK_LAUNCH("ln_bwd_reduce");
     return MGX_OK;
 }
@@ -435,19 +441,19 @@ extern "C" int mgx_ln_residual_fwd(const void* a, const void* res, const float* 
 
 extern "C" int mgx_ln_residual_bwd(const void* dy, const void* dy2, const void* z, const float* mean,
                                    const float* rstd, const float* gamma, void* dz, void* da, float* dgamma,
-                                   float* dbeta, float* partial, long T, int d, float p_drop, unsigned long long seed,
-                                   int dtype, void* stream) {
+                                   float* dbeta, float* dsum, float* partial, long T, int d, float p_drop,
+                                   unsigned long long seed, int dtype, void* stream) {
     MGX_REQUIRE(dy && z && mean && rstd && gamma && dz && dgamma && dbeta && partial, MGX_EINVAL,
                 "mgx_ln_residual_bwd: null pointer");
     MGX_REQUIRE(T > 0 && d > 0, MGX_EINVAL, "mgx_ln_residual_bwd: T=%ld d=%d", T, d);
     MGX_REQUIRE(dtype == MGX_F32 || dtype == MGX_BF16, MGX_EINVAL, "mgx_ln_residual_bwd: bad dtype %d", dtype);
     const int N = dtype == MGX_F32 ? 4 : 8;
     MGX_REQUIRE(d % N == 0 && d <= 64 * N * 8, MGX_EUNSUPPORTED, "mgx_ln_residual_bwd: unsupported d=%d", d);
-    MGX_REQUIRE((size_t)8 * d * sizeof(float) <= 64 * 1024, MGX_EUNSUPPORTED, "mgx_ln_residual_bwd: d=%d too large", d);
+    MGX_REQUIRE((size_t)4 * d * sizeof(float) <= 64 * 1024, MGX_EUNSUPPORTED, "mgx_ln_residual_bwd: d=%d too large", d);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MGX_F32)
-        return ln_bwd_launch<float>(dy, dy2, z, mean, rstd, gamma, dz, da, dgamma, dbeta, partial, T, d, p_drop, seed, st);
-    return ln_bwd_launch<bf16_t>(dy, dy2, z, mean, rstd, gamma, dz, da, dgamma, dbeta, partial, T, d, p_drop, seed, st);
+        return ln_bwd_launch<float>(dy, dy2, z, mean, rstd, gamma, dz, da, dgamma, dbeta, dsum, partial, T, d, p_drop, seed, st);
+    return ln_bwd_launch<bf16_t>(dy, dy2, z, mean, rstd, gamma, dz, da, dgamma, dbeta, dsum, partial, T, d, p_drop, seed, st);
 }
 
 extern "C" int mgx_bias_act_fwd(const void* u, const float* bias, void* pre, void* h, long T, int n, int act,
@@ -488,7 +494,7 @@ extern "C" int mgx_bias_act_bwd(const void* dh, const void* pre, void* dpre, flo
         hipLaunchKernelGGL((bias_act_bwd_kernel<bf16_t>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)dh,
                            (const bf16_t*)pre, (bf16_t*)dpre, partial, T, n, act, p_drop, seed);
     MGX_CHECK_LAUNCH("bias_act_bwd");
-    hipLaunchKernelGGL(column_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial, dbias, dbias, nblk, n, 1);
+    hipLaunchKernelGGL(column_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial, dbias, dbias, dbias, nblk, n, 1);
     MGX_CHECK_LAUNCH("bias_act_bwd_reduce");
     return MGX_OK;
 }

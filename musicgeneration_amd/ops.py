@@ -162,8 +162,9 @@ def ln_residual_fwd(a, res, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, save=True
 _PARTIAL_ROWS = lib.mgx_ln_bwd_partial_rows()
 
 
-def ln_residual_bwd(dy, dy2, z, mean, rstd, gamma, p_drop=0.0, seed=0):
-    """Returns (dz, da, dgamma, dbeta); da is dz when p_drop == 0."""
+def ln_residual_bwd(dy, dy2, z, mean, rstd, gamma, p_drop=0.0, seed=0, want_dsum=False):
+    """Returns (dz, da, dgamma, dbeta[, dsum]); da is dz when p_drop == 0; dsum = da.sum(0) in fp32
+    (the bias gradient of the projection feeding the branch), produced by the same pass."""
     _need(dy, "dy", z.dtype)
     if dy2 is not None:
         _need(dy2, "dy2", z.dtype)
@@ -175,10 +176,13 @@ def ln_residual_bwd(dy, dy2, z, mean, rstd, gamma, p_drop=0.0, seed=0):
     da = torch.empty_like(z) if p_drop > 0 else dz
     dgamma = torch.empty(d, dtype=torch.float32, device=z.device)
     dbeta = torch.empty(d, dtype=torch.float32, device=z.device)
-    partial = torch.empty(_PARTIAL_ROWS * 2 * d, dtype=torch.float32, device=z.device)
+    dsum = torch.empty(d, dtype=torch.float32, device=z.device) if want_dsum else None
+    partial = torch.empty(_PARTIAL_ROWS * 3 * d, dtype=torch.float32, device=z.device)
     check(lib.mgx_ln_residual_bwd(_p(dy), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(da), _p(dgamma),
-                                  _p(dbeta), _p(partial), T, d, float(p_drop), seed, _dt(z), _stream()),
+                                  _p(dbeta), _p(dsum), _p(partial), T, d, float(p_drop), seed, _dt(z), _stream()),
           "mgx_ln_residual_bwd")
+    if want_dsum:
+        return dz, da, dgamma, dbeta, dsum
     return dz, da, dgamma, dbeta
 
 
@@ -411,16 +415,14 @@ class _DecoderBlock(torch.autograd.Function):
         T = B * S
         f32 = torch.float32
         dh2 = dh2.reshape(T, d).contiguous()
-        dz2, _, dg2, dbe2 = ln_residual_bwd(dh2, None, z2, mean2, rstd2, W.m_g2)
-        db2 = dz2.sum(0, dtype=f32)
+        dz2, _, dg2, dbe2, db2 = ln_residual_bwd(dh2, None, z2, mean2, rstd2, W.m_g2, want_dsum=True)
         dw2 = gemm_tn(dz2, hact) if "dw2" in mgx else torch.mm(dz2.t(), hact)          # [d, ff]
         dact = gemm_nt(dz2, W.w2_t) if "dact" in mgx else torch.mm(dz2, W.w2)           # [T, ff]
         dpre, db1 = bias_act_bwd(dact, pre, act, p, seed2)
         dw1 = gemm_tn(dpre, h1) if "dw1" in mgx else torch.mm(dpre.t(), h1)             # [ff, d]
         dh1 = gemm_nt(dpre, W.w1_t) if "dh1" in mgx else torch.mm(dpre, W.w1)           # [T, d]
-        dz1, da1, dg1, dbe1 = ln_residual_bwd(dh1, dz2, z1, mean1, rstd1, W.m_g1, p, seed1)
+        dz1, da1, dg1, dbe1, dbp = ln_residual_bwd(dh1, dz2, z1, mean1, rstd1, W.m_g1, p, seed1, want_dsum=True)
         a2 = a.view(T, d)
-        dbp = da1.sum(0, dtype=f32)
         dwp = gemm_tn(a2, da1) if "dwp" in mgx else torch.mm(a2.t(), da1)               # [d, d]
         da = (gemm_nt(da1, W.wp) if "da" in mgx else torch.mm(da1, W.wp.t())).view(B, S, d)   # da1 @ wp^T
         if E is None:

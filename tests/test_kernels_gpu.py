@@ -213,6 +213,10 @@ def test_layernorm_residual(T, d, dtype, with_res):
     assert gu.rel_err(dz.float(), a_r.grad) < gtol
     assert gu.rel_err(dg, gm.grad) < gtol
     assert gu.rel_err(db, bt.grad) < gtol
+    # fused bias gradient of the branch: column sums of da, same pass, same dz/dgamma/dbeta
+    dz3, da3, dg3, db3, dsum = ops.ln_residual_bwd(dy.cuda(), dy2.cuda(), z, mean, rstd, gamma.cuda(), want_dsum=True)
+    assert torch.equal(dz3, dz) and torch.equal(dg3, dg) and torch.equal(db3, db)
+    assert gu.rel_err(dsum, a_r.grad.sum(0)) < (1e-4 if dtype == torch.float32 else BF16_TOL)
     # inference form: no saved tensors, same y
     y2, z2, _, _ = ops.ln_residual_fwd(a.cuda(), None if res is None else res.cuda(), gamma.cuda(), beta.cuda(), save=False)
     assert z2 is None
@@ -235,6 +239,11 @@ def test_layernorm_dropout_mask_consistent():
     dz, da, _, _ = ops.ln_residual_bwd(torch.randn(T, d).cuda(), None, z, mean, rstd, gamma, p, seed)
     assert torch.equal(da != 0, kept & (dz != 0))
     assert torch.allclose(da[kept], dz[kept] / (1 - p))
+    *_, dsum = ops.ln_residual_bwd(torch.randn(T, d, generator=torch.Generator().manual_seed(1)).cuda(), None, z, mean,
+                                   rstd, gamma, p, seed, want_dsum=True)
+    _, da2, _, _ = ops.ln_residual_bwd(torch.randn(T, d, generator=torch.Generator().manual_seed(1)).cuda(), None, z, mean,
+                                       rstd, gamma, p, seed)
+    assert torch.allclose(dsum, da2.sum(0), rtol=1e-4, atol=1e-4)      # sums the masked gradient, not dz
 
 
 @pytest.mark.parametrize("T,n", [(50, 128), (33, 4096), (257, 512)])
