@@ -318,9 +318,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmArgs g) {
     const int wm = w >> 2, wn = w & 3;
     const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM;
     const int ntile = nbm * nbn;
-    const int split = blockIdx.x / ntile;                     // all tiles of one K split are adjacent
-    const int tile = blockIdx.x - split * ntile;
-    const int bm = tile / nbn, bn = tile - bm * nbn;
+    // Workgroups that share an XCD (blockIdx % 8) take a contiguous run of (split, tile) pairs, the
+    // smaller tile dimension fastest: the ~32 workgroups resident on one XCD then cover a compact
+    // rectangle of tiles of ONE K split and walk K together, so every A / B panel slice is fetched
+    // into that XCD's L2 once and re-used by the rectangle's row / column (the operand stream of
+    // this kernel is otherwise ~2 GB per launch from beyond L2).
+    const int wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = wid / ntile;
+    const int tile = wid - split * ntile;
+    int bm, bn;
+    if (nbm <= nbn) {
+        bn = tile / nbm;
+        bm = tile - bn * nbm;
+    } else {
+        bm = tile / nbn;
+        bn = tile - bm * nbn;
+    }
     const int m0 = bm * BM, n0 = bn * BN;
     const int kbeg = split * g.ksplit_len;
     const int kend = min(g.K, kbeg + g.ksplit_len);
@@ -338,17 +351,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmArgs g) {
         acol[i] = (piece >> 4) * 128 + ch * 8;
     }
     typedef __attribute__((address_space(3))) void lds_void;
-    auto stage = [&](int k0, int buf) {
+    auto stage_piece = [&](int k0, int buf, int i) {
         char* sa = smem + buf * STAGE_BYTES + 4096 * w;
+        // rows past the end of this split read a 16-byte block of zeros instead
+        const bool ok = k0 + arow[i] < kend;
+        const bf16_t* pa = ok ? g.A + (long)(k0 + arow[i]) * g.lda + min(m0 + acol[i], g.M - 8) : g_zero16;
+        const bf16_t* pb = ok ? g.B + (long)(k0 + arow[i]) * g.ldb + min(n0 + acol[i], g.N - 8) : g_zero16;
+        __builtin_amdgcn_global_load_lds((const void*)pa, (lds_void*)(sa + 1024 * i), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)pb, (lds_void*)(sa + TILE_BYTES + 1024 * i), 16, 0, 0);
+    };
+    auto stage = [&](int k0, int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // rows past the end of this split read a 16-byte block of zeros instead
-            const bool ok = k0 + arow[i] < kend;
-            const bf16_t* pa = ok ? g.A + (long)(k0 + arow[i]) * g.lda + min(m0 + acol[i], g.M - 8) : g_zero16;
-            const bf16_t* pb = ok ? g.B + (long)(k0 + arow[i]) * g.ldb + min(n0 + acol[i], g.N - 8) : g_zero16;
-            __builtin_amdgcn_global_load_lds((const void*)pa, (lds_void*)(sa + 1024 * i), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const void*)pb, (lds_void*)(sa + TILE_BYTES + 1024 * i), 16, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i) stage_piece(k0, buf, i);
     };
 
     // transposed-read lane offsets (see attn_mfma.hip LaneAddr): columns on the lanes, k reduced
@@ -368,28 +382,60 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Main loop: same two-group schedule as gemm_nt_kernel (waves 0-3 and 4-7 run one interval apart:
+    // one group reads every fragment of its K tile into registers while the other issues 32 MFMAs);
+    // the fragment reads are transposed (ds_read_b64_tr_b16 pairs) because both operands are K-major.
     const int nk = (kend - kbeg + BK - 1) / BK;
+    const int grp = __builtin_amdgcn_readfirstlane(w) >> 2;
     stage(kbeg, 0);
-    __syncthreads();
+    if (grp == 1 && nk > 1) {
+        stage(kbeg + BK, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nk; ++kt) {
         const char* s = smem + (kt & 1) * STAGE_BYTES;
-        if (kt + 1 < nk) stage(kbeg + (kt + 1) * BK, (kt + 1) & 1);
+        // ---- READ interval
+        bf16x8 bf[4][2], af[4][4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {                      // 16 k per step: 8-row groups 2ks, 2ks+1
             const int k0o = 2048 * (2 * ks), k1o = 2048 * (2 * ks + 1);
-            bf16x8 bf[2], af[4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = lds_tr_pair(s + b_base + 512 * j + tr0 + k0o, s + b_base + 512 * j + tr1 + k1o);
+            for (int j = 0; j < 2; ++j)
+                bf[ks][j] = lds_tr_pair(s + b_base + 512 * j + tr0 + k0o, s + b_base + 512 * j + tr1 + k1o);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = lds_tr_pair(s + a_base + 512 * i + tr0 + k0o, s + a_base + 512 * i + tr1 + k1o);
+            for (int i = 0; i < 4; ++i)
+                af[ks][i] = lds_tr_pair(s + a_base + 512 * i + tr0 + k0o, s + a_base + 512 * i + tr1 + k1o);
+        }
+        if (grp == 0 && kt + 1 < nk) stage(kbeg + (kt + 1) * BK, (kt + 1) & 1);
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA interval (group 1 issues the LDS-DMA of tile kt+2 between its MFMAs)
+        const bool g1stage = grp == 1 && kt + 2 < nk;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+            if (g1stage) stage_piece(kbeg + (kt + 2) * BK, kt & 1, ks);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
     // fp32 slab store: D[row = n][col = m]: lane = m, 4 consecutive n per register group (16-B stores)
     float* C = reinterpret_cast<float*>(g.C) + (long)split * g.M * g.ldc;
 #pragma unroll
@@ -453,7 +499,9 @@ extern "C" int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2
 
 extern "C" long mgx_gemm_tn_workspace_floats(int M, int N, int K, int* splits_out) {
     const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    int splits = (int)((512 + tiles - 1) / tiles);          // aim at ~2 workgroups per CU
+    // one workgroup per CU (128 KiB of LDS each) and equal work per workgroup: a single round of at
+    // most 256 workgroups has no tail and writes the fewest fp32 slabs
+    int splits = (int)(256 / tiles);
     const int max_splits = (K + 4 * BK - 1) / (4 * BK);     // at least 4 K tiles per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

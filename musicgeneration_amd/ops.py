@@ -349,9 +349,9 @@ import os as _os
 # bf16 projections.  "mgx": every projection on the hand-written MFMA GEMMs; "torch": every projection a
 # library GEMM (hipBLASLt); "auto" (default): per site, whichever measured faster on MI355X at the
 # training shapes (tools/gemm_bench.py): the MLP up-projection with its fused bias+GELU+dropout epilogue
-# and the c_proj weight gradient run on libmgx, the rest on the library.
+# and every weight gradient (TN, split-K, fp32 output) run on libmgx, the rest on the library.
 GEMM_BACKEND = _os.environ.get("MGX_GEMM", "auto")
-_AUTO_SITES = {"mlp1", "dwp"}
+_AUTO_SITES = {"mlp1", "dwp", "dw1", "dw2", "dwqkv"}
 
 
 def _mgx_sites(x2, d, ff):
