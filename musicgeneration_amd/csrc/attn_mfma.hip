@@ -17,6 +17,7 @@
 // the MFMAs of tile t.  LDS image: 8-row x 32-column sub-tiles (512 B) with an
 // XOR on the 16-byte chunk index, conflict-free for both the row reads and the
 // transposed reads (cdna_hip_programming.md T10 image (a)).
+#include <type_traits>
 #include "attn_mfma_common.h"
 
 namespace {
@@ -360,22 +361,33 @@ __global__ __launch_bounds__(64 * NW, MGX_DKV_OCC) void attn_bwd_dkv_mfma_kernel
     store_tile(t0 * 64, 0);
     if (t0 + 1 < ntiles) load_tile(t0 * 64 + 64);
     __syncthreads();
-    for (int t = t0; t < ntiles; ++t) {
+    // One 64-query tile.  DIAG = true: the tile may touch the causal diagonal of this wave's keys
+    // (wave-uniform skips + per-element mask); DIAG = false: every query sees every key of the
+    // workgroup, the body is branch-free.  Only the first two tiles of a workgroup can be diagonal:
+    // keeping them out of the steady-state loop keeps the dK/dV accumulators in one register class
+    // there (with the skips inside the loop hipcc copied all 128 of them AGPR<->VGPR every tile:
+    // 540 v_accvgpr moves per 64 MFMAs; the peeled loop runs the backward 16 % faster).
+    // A hand-pipelined five-phase body (sched_group_barrier) was measured and is not kept: no gain
+    // at dh 128 (the wave is issue-bound: ~480 non-MFMA instructions per 64 MFMAs) and slower at dh 64.
+    auto tile_body = [&](int t, auto diag_tag) {
+        constexpr bool DIAG = decltype(diag_tag)::value;
         const int i0 = t * 64;
         const int buf = (t - t0) & 1;
         const char* Qs = smem + buf * 2 * TB;
         const char* Gs = Qs + TB;
         const float* Ls = stats + buf * 128;
         const float* Dn = Ls + 64;
+#ifndef MGX_ABL_NOSTAGE                   // timing experiment only: results are wrong
         if (t + 1 < ntiles) store_tile(i0 + 64, buf ^ 1);
         if (t + 2 < ntiles) load_tile(i0 + 128);
-        if (i0 + 63 >= jw0) {                                      // wave-uniform
+#endif
+        if (!DIAG || i0 + 63 >= jw0) {                             // wave-uniform
             const float cj = sb * (float)(j - i0);
-            const bool diag = i0 < jw0 + 31;
+            const bool diag = DIAG && i0 < jw0 + 31;
             const int di = j - i0 - 4 * h5;                        // masked when row-part < di
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) {
-                if (i0 + 32 * tb + 31 < jw0) continue;             // block entirely above the diagonal
+                if (DIAG && i0 + 32 * tb + 31 < jw0) continue;     // block entirely above the diagonal
                 f32x16 sc, dp;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -394,8 +406,12 @@ __global__ __launch_bounds__(64 * NW, MGX_DKV_OCC) void attn_bwd_dkv_mfma_kernel
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+#ifdef MGX_ABL_NOEXP                     // timing experiment only: results are wrong
+                    float p = sc[r] * c;
+#else
                     float p = fast_exp2(sc[r] * c);
-                    if (diag && (32 * tb + (r & 3) + 8 * (r >> 2) < di)) p = 0.f;
+#endif
+                    if (DIAG && diag && (32 * tb + (r & 3) + 8 * (r >> 2) < di)) p = 0.f;
                     sc[r] = p;
                     dp[r] = p * dp[r] * scale;
                 }
@@ -414,7 +430,10 @@ __global__ __launch_bounds__(64 * NW, MGX_DKV_OCC) void attn_bwd_dkv_mfma_kernel
             }
         }
         __syncthreads();
-    }
+    };
+    const int tdiag = min(ntiles, t0 + (KB + 63) / 64);            // tiles [t0, tdiag) can touch the diagonal
+    for (int t = t0; t < tdiag; ++t) tile_body(t, std::true_type{});
+    for (int t = tdiag; t < ntiles; ++t) tile_body(t, std::false_type{});
     if (jok) {
         bf16_t* op = dqkv + ((long)b * S + j) * rs + (long)h * DH;
 #pragma unroll
