@@ -101,8 +101,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_mfma_kernel(const bf16_t*
             for (int ks = 0; ks < DH / 16; ++ks)
 #pragma unroll
                 for (int tb = 0; tb < 2; ++tb)
+#ifdef MGX_ABL_FWD_NOLDS                 // timing experiment only: results are wrong
+                    s[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[(ks + 1) % (DH / 16)], qf[ks], s[tb], 0, 0, 0);
+#else
                     s[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(Ks + la.row_read(tb, ks)), qf[ks],
                                                                    s[tb], 0, 0, 0);
+#endif
             if (j0 + 63 > qw0) {                          // diagonal tile: causal mask
                 const int dj = qi - j0 - 4 * h5;          // key offset (r-part) must be <= dj
 #pragma unroll
@@ -137,7 +141,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_mfma_kernel(const bf16_t*
             for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+#ifdef MGX_ABL_FWD_NOEXP                 // timing experiment only: results are wrong
+                    const float p = s[tb][r];
+#else
                     const float p = fast_exp2(fmaf(s[tb][r], c, -mc));
+#endif
                     s[tb][r] = p;
                     psum += p;
                 }
@@ -149,7 +157,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_mfma_kernel(const bf16_t*
                     const bf16x8 pf = pack8(s[tb], 8 * s2);
 #pragma unroll
                     for (int d = 0; d < DH / 32; ++d) {
+#ifdef MGX_ABL_FWD_NOLDS                 // timing experiment only: results are wrong
+                        const bf16x8 vf = qf[(4 * tb + 2 * s2 + d) % (DH / 16)];
+#else
                         const bf16x8 vf = lds_read_tr_pair(Vs + la.tr_read(tb, s2, 0, d), Vs + la.tr_read(tb, s2, 1, d));
+#endif
                         o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
                     }
                 }
