@@ -10,7 +10,7 @@
 
 namespace {
 
-constexpr int PARTIAL_ROWS = 512;       // row-blocks of the two-stage column reductions
+constexpr int PARTIAL_ROWS = 512;  // row-blocks of the two-stage column reductions
 
 template <typename T> struct Vec;
 template <> struct Vec<float> {
@@ -266,9 +266,22 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
     const float z = x * 0.70710678118654752440f;
     return 0.5f * x * (1.f + (FAST ? erf_fast(z) : erff(z)));
 }
+// d/dx gelu(x) = Phi(x) + x phi(x); erf(x/sqrt2) and phi(x) share the one exp(-x^2/2)
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    const float az = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);     // exp(-x^2/2)
+    const float erfv = copysignf(fmaf(-poly * t, e, 1.f), x);
+    return fmaf(x * 0.3989422804014327f, e, fmaf(0.5f, erfv, 0.5f));
+}
 template <bool FAST>
 __device__ __forceinline__ float act_grad(float x, int act) {
     if (act == MGX_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+    if (FAST) return gelu_grad_fast(x);
     const float z = x * 0.70710678118654752440f;
     const float cdf = 0.5f * (1.f + (FAST ? erf_fast(z) : erff(z)));
     const float pdf = 0.3989422804014327f * (FAST ? __builtin_amdgcn_exp2f(-0.5f * x * x * 1.4426950408889634f)
@@ -276,48 +289,66 @@ __device__ __forceinline__ float act_grad(float x, int act) {
     return cdf + x * pdf;
 }
 
-template <typename T>
+// Activation and dropout are compile-time: with a run-time `act` hipcc branched per element
+// (one small basic block per value) and the kernels ran VALU/branch-bound at 2.7-3.9 TB/s.
+// Block b handles rows b, b+grid, ...; thread t handles the 16-byte column vectors t, t+256, ...;
+// U rows are loaded before the first is used.
+template <typename T, int ACT, bool DROP>
 __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const T* __restrict__ u, const float* __restrict__ bias,
-                                                            T* __restrict__ pre, T* __restrict__ h, long total, int n,
-                                                            int act, float p_drop, unsigned long long seed) {
-    constexpr int N = Vec<T>::N;
+                                                            T* __restrict__ pre, T* __restrict__ h, long T_rows, int n,
+                                                            float p_drop, unsigned long long seed) {
+    constexpr int N = Vec<T>::N, U = 4;
     constexpr bool FAST = sizeof(T) == 2;
     const unsigned thr16 = mgx_drop_thr16(p_drop);
     const float keep_scale = mgx_keep_scale(thr16);
-    for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * N; e < total; e += (long)gridDim.x * 256 * N) {
-        const int col = (int)(e % n);
-        float v[N], o[N];
-        load_vec<T, N>(u + e, v);
+    for (int col = threadIdx.x * N; col < n; col += 256 * N) {
+        float bv[N];
 #pragma unroll
-        for (int k = 0; k < N; ++k) v[k] += bias[col + k];
-        if (pre) {
-            store_vec<T, N>(pre + e, v);
+        for (int k = 0; k < N; ++k) bv[k] = bias[col + k];
+        for (long row0 = blockIdx.x; row0 < T_rows; row0 += (long)U * gridDim.x) {
+            float v[U][N];
 #pragma unroll
-            for (int k = 0; k < N; ++k) v[k] = to_f32(from_f32<T>(v[k]));
-        }
+            for (int q = 0; q < U; ++q) {
+                const long row = min(row0 + (long)q * gridDim.x, T_rows - 1);
+                load_vec<T, N>(u + row * n + col, v[q]);
+            }
 #pragma unroll
-        for (int k = 0; k < N; k += 2) {
-            o[k] = act_fwd<FAST>(v[k], act);
-            o[k + 1] = act_fwd<FAST>(v[k + 1], act);
-            if (p_drop > 0.f) {
-                bool k0, k1;
-                mgx_keep_pair(seed, (unsigned long long)(e + k), thr16, k0, k1);
-                o[k] = k0 ? o[k] * keep_scale : 0.f;
-                o[k + 1] = k1 ? o[k + 1] * keep_scale : 0.f;
+            for (int q = 0; q < U; ++q) {
+                const long row = row0 + (long)q * gridDim.x;
+                if (row < T_rows) {
+                    const long e = row * n + col;
+                    float o[N];
+#pragma unroll
+                    for (int k = 0; k < N; ++k) v[q][k] += bv[k];
+                    if (pre) {
+                        store_vec<T, N>(pre + e, v[q]);
+#pragma unroll
+                        for (int k = 0; k < N; ++k) v[q][k] = to_f32(from_f32<T>(v[q][k]));
+                    }
+#pragma unroll
+                    for (int k = 0; k < N; k += 2) {
+                        o[k] = act_fwd<FAST>(v[q][k], ACT);
+                        o[k + 1] = act_fwd<FAST>(v[q][k + 1], ACT);
+                        if (DROP) {
+                            bool k0, k1;
+                            mgx_keep_pair(seed, (unsigned long long)(e + k), thr16, k0, k1);
+                            o[k] = k0 ? o[k] * keep_scale : 0.f;
+                            o[k + 1] = k1 ? o[k + 1] * keep_scale : 0.f;
+                        }
+                    }
+                    store_vec<T, N>(h + e, o);
+                }
             }
         }
-        store_vec<T, N>(h + e, o);
     }
 }
 
 // dpre = dh * mask * act'(pre); partial[blk][n] column sums for dbias.
-// Block handles rows blk, blk+grid, ...; thread t handles column vectors t, t+256, ...
-template <typename T>
+template <typename T, int ACT, bool DROP>
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ pre,
                                                             T* __restrict__ dpre, float* __restrict__ partial,
-                                                            long T_rows, int n, int act, float p_drop,
-                                                            unsigned long long seed) {
-    constexpr int N = Vec<T>::N;
+                                                            long T_rows, int n, float p_drop, unsigned long long seed) {
+    constexpr int N = Vec<T>::N, U = 4;
     constexpr bool FAST = sizeof(T) == 2;
     const unsigned thr16 = mgx_drop_thr16(p_drop);
     const float keep_scale = mgx_keep_scale(thr16);
@@ -325,30 +356,74 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
         float acc[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) acc[k] = 0.f;
-#pragma unroll 4
-        for (long row = blockIdx.x; row < T_rows; row += gridDim.x) {
-            const long e = row * n + col;
-            float g[N], x[N];
-            load_vec<T, N>(dh + e, g);
-            load_vec<T, N>(pre + e, x);
+        for (long row0 = blockIdx.x; row0 < T_rows; row0 += (long)U * gridDim.x) {
+            float g[U][N], x[U][N];
 #pragma unroll
-            for (int k = 0; k < N; k += 2) {
-                if (p_drop > 0.f) {
-                    bool k0, k1;
-                    mgx_keep_pair(seed, (unsigned long long)(e + k), thr16, k0, k1);
-                    g[k] = k0 ? g[k] * keep_scale : 0.f;
-                    g[k + 1] = k1 ? g[k + 1] * keep_scale : 0.f;
-                }
-                g[k] *= act_grad<FAST>(x[k], act);
-                g[k + 1] *= act_grad<FAST>(x[k + 1], act);
+            for (int q = 0; q < U; ++q) {
+                const long row = min(row0 + (long)q * gridDim.x, T_rows - 1);
+                load_vec<T, N>(dh + row * n + col, g[q]);
+                load_vec<T, N>(pre + row * n + col, x[q]);
             }
-            store_vec<T, N>(dpre + e, g);
 #pragma unroll
-            for (int k = 0; k < N; ++k) acc[k] += to_f32(from_f32<T>(g[k]));
+            for (int q = 0; q < U; ++q) {
+                const long row = row0 + (long)q * gridDim.x;
+                if (row < T_rows) {
+                    const long e = row * n + col;
+#pragma unroll
+                    for (int k = 0; k < N; k += 2) {
+                        if (DROP) {
+                            bool k0, k1;
+                            mgx_keep_pair(seed, (unsigned long long)(e + k), thr16, k0, k1);
+                            g[q][k] = k0 ? g[q][k] * keep_scale : 0.f;
+                            g[q][k + 1] = k1 ? g[q][k + 1] * keep_scale : 0.f;
+                        }
+                        g[q][k] *= act_grad<FAST>(x[q][k], ACT);
+                        g[q][k + 1] *= act_grad<FAST>(x[q][k + 1], ACT);
+                    }
+                    store_vec<T, N>(dpre + e, g[q]);
+#pragma unroll
+                    for (int k = 0; k < N; ++k) acc[k] += to_f32(from_f32<T>(g[q][k]));
+                }
+            }
         }
 #pragma unroll
         for (int k = 0; k < N; ++k) partial[(size_t)blockIdx.x * n + col + k] = acc[k];
     }
+}
+
+template <typename T>
+int bias_act_fwd_launch(const void* u, const float* bias, void* pre, void* h, long T_rows, int n, int act,
+                        float p_drop, unsigned long long seed, hipStream_t st) {
+    const int nblk = (int)(T_rows < 8192 ? T_rows : 8192);
+#define MGX_BA_FWD(ACT, DROP)                                                                                     \
+    hipLaunchKernelGGL((bias_act_fwd_kernel<T, ACT, DROP>), dim3(nblk), dim3(256), 0, st, (const T*)u, bias, (T*)pre, \
+                       (T*)h, T_rows, n, p_drop, seed)
+    const bool drop = p_drop > 0.f;
+    if (act == MGX_ACT_GELU) {
+        if (drop) MGX_BA_FWD(MGX_ACT_GELU, true); else MGX_BA_FWD(MGX_ACT_GELU, false);
+    } else {
+        if (drop) MGX_BA_FWD(MGX_ACT_RELU, true); else MGX_BA_FWD(MGX_ACT_RELU, false);
+    }
+#undef MGX_BA_FWD
+    MGX_CHECK_LAUNCH("bias_act_fwd");
+    return MGX_OK;
+}
+
+template <typename T>
+int bias_act_bwd_launch(const void* dh, const void* pre, void* dpre, float* partial, long T_rows, int n, int nblk,
+                        int act, float p_drop, unsigned long long seed, hipStream_t st) {
+#define MGX_BA_BWD(ACT, DROP)                                                                                      \
+    hipLaunchKernelGGL((bias_act_bwd_kernel<T, ACT, DROP>), dim3(nblk), dim3(256), 0, st, (const T*)dh, (const T*)pre, \
+                       (T*)dpre, partial, T_rows, n, p_drop, seed)
+    const bool drop = p_drop > 0.f;
+    if (act == MGX_ACT_GELU) {
+        if (drop) MGX_BA_BWD(MGX_ACT_GELU, true); else MGX_BA_BWD(MGX_ACT_GELU, false);
+    } else {
+        if (drop) MGX_BA_BWD(MGX_ACT_RELU, true); else MGX_BA_BWD(MGX_ACT_RELU, false);
+    }
+#undef MGX_BA_BWD
+    MGX_CHECK_LAUNCH("bias_act_bwd");
+    return MGX_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -464,18 +539,9 @@ extern "C" int mgx_bias_act_fwd(const void* u, const float* bias, void* pre, voi
     MGX_REQUIRE(act == MGX_ACT_GELU || act == MGX_ACT_RELU, MGX_EINVAL, "mgx_bias_act_fwd: bad act %d", act);
     const int N = dtype == MGX_F32 ? 4 : 8;
     MGX_REQUIRE(n % N == 0, MGX_EUNSUPPORTED, "mgx_bias_act_fwd: n=%d must be a multiple of %d", n, N);
-    const long total = T * n;
-    long blocks = (total / N + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MGX_F32)
-        hipLaunchKernelGGL((bias_act_fwd_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)u, bias,
-                           (float*)pre, (float*)h, total, n, act, p_drop, seed);
-    else
-        hipLaunchKernelGGL((bias_act_fwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)u,
-                           bias, (bf16_t*)pre, (bf16_t*)h, total, n, act, p_drop, seed);
-    MGX_CHECK_LAUNCH("bias_act_fwd");
-    return MGX_OK;
+    if (dtype == MGX_F32) return bias_act_fwd_launch<float>(u, bias, pre, h, T, n, act, p_drop, seed, st);
+    return bias_act_fwd_launch<bf16_t>(u, bias, pre, h, T, n, act, p_drop, seed, st);
 }
 
 extern "C" int mgx_bias_act_bwd(const void* dh, const void* pre, void* dpre, float* dbias, float* partial, long T,
@@ -487,13 +553,11 @@ extern "C" int mgx_bias_act_bwd(const void* dh, const void* pre, void* dpre, flo
     MGX_REQUIRE(n % N == 0, MGX_EUNSUPPORTED, "mgx_bias_act_bwd: n=%d must be a multiple of %d", n, N);
     const int nblk = (int)(T < PARTIAL_ROWS ? T : PARTIAL_ROWS);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MGX_F32)
-        hipLaunchKernelGGL((bias_act_bwd_kernel<float>), dim3(nblk), dim3(256), 0, st, (const float*)dh,
-                           (const float*)pre, (float*)dpre, partial, T, n, act, p_drop, seed);
-    else
-        hipLaunchKernelGGL((bias_act_bwd_kernel<bf16_t>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)dh,
-                           (const bf16_t*)pre, (bf16_t*)dpre, partial, T, n, act, p_drop, seed);
-    MGX_CHECK_LAUNCH("bias_act_bwd");
+    MGX_REQUIRE(act == MGX_ACT_GELU || act == MGX_ACT_RELU, MGX_EINVAL, "mgx_bias_act_bwd: bad act %d", act);
+    const int rc = dtype == MGX_F32
+                       ? bias_act_bwd_launch<float>(dh, pre, dpre, partial, T, n, nblk, act, p_drop, seed, st)
+                       : bias_act_bwd_launch<bf16_t>(dh, pre, dpre, partial, T, n, nblk, act, p_drop, seed, st);
+    if (rc != MGX_OK) return rc;
     hipLaunchKernelGGL(column_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, partial, dbias, dbias, dbias, nblk, n, 1);
     MGX_CHECK_LAUNCH("bias_act_bwd_reduce");
     return MGX_OK;

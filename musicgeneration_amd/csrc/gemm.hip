@@ -90,6 +90,9 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // =============================================================================================
 // NT kernel
 // =============================================================================================
+// ACT: -1 none, MGX_ACT_*; DROP: dropout after the activation.  Compile-time: with run-time switches
+// hipcc branched per element in the epilogue.
+template <int ACT, bool DROP>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g) {
 
     // ---- epilogue through LDS: wave-private [64 rows][64 cols] slab, two passes (mi pairs) ----
     char* cs = smem + w * (64 * CPITCH);
-    const bool has_act = g.act >= 0;
+    constexpr bool has_act = ACT >= 0;
     const unsigned thr16 = mgx_drop_thr16(g.p_drop);
     const float keep_scale = mgx_keep_scale(thr16);
 #pragma unroll
@@ -281,9 +284,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g) {
                     for (int k = 0; k < 8; k += 2) {
                         // the activation sees the stored (rounded) pre-activation, as the unfused kernel does
                         float x0 = (float)o[k], x1 = (float)o[k + 1];
-                        float y0 = g.act == MGX_ACT_RELU ? fmaxf(x0, 0.f) : gelu_fast(x0);
-                        float y1 = g.act == MGX_ACT_RELU ? fmaxf(x1, 0.f) : gelu_fast(x1);
-                        if (g.p_drop > 0.f) {
+                        float y0 = ACT == MGX_ACT_RELU ? fmaxf(x0, 0.f) : gelu_fast(x0);
+                        float y1 = ACT == MGX_ACT_RELU ? fmaxf(x1, 0.f) : gelu_fast(x1);
+                        if (DROP) {
                             bool k0, k1;
                             mgx_keep_pair(g.seed, (unsigned long long)((long)m * g.N + n + k), thr16, k0, k1);
                             y0 = k0 ? y0 * keep_scale : 0.f;
@@ -492,7 +495,13 @@ extern "C" int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2
                act, p_drop, seed, 0};
     const long nblk = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     MGX_REQUIRE(nblk < (1L << 31), MGX_EUNSUPPORTED, "mgx_gemm_nt_bf16: too many tiles");
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)nblk), dim3(NTHREADS), 0, (hipStream_t)stream, g);
+#define MGX_NT(ACT, DROP) \
+    hipLaunchKernelGGL((gemm_nt_kernel<ACT, DROP>), dim3((unsigned)nblk), dim3(NTHREADS), 0, (hipStream_t)stream, g)
+    const bool drop = p_drop > 0.f;
+    if (act < 0) MGX_NT(-1, false);
+    else if (act == MGX_ACT_GELU) { if (drop) MGX_NT(MGX_ACT_GELU, true); else MGX_NT(MGX_ACT_GELU, false); }
+    else { if (drop) MGX_NT(MGX_ACT_RELU, true); else MGX_NT(MGX_ACT_RELU, false); }
+#undef MGX_NT
     MGX_CHECK_LAUNCH("gemm_nt");
     return MGX_OK;
 }

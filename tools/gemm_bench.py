@@ -22,3 +22,12 @@ for name, (K, M, N) in {"dWqkv": (T, d, 3 * d), "dWp": (T, d, d), "dW1": (T, ff,
     fl = 2.0 * M * N * K
     t1 = timeit(lambda: ops.gemm_tn(a, b)); t2 = timeit(lambda: torch.mm(a.t(), b))
     print(f"TN {name:5s} M={M} N={N} K={K}: mgx {t1*1e3:7.1f} us {fl/t1/1e9:7.1f} TF | torch {t2*1e3:7.1f} us {fl/t2/1e9:7.1f} TF")
+# fused epilogue (mlp1: bias + GELU + dropout, two outputs)
+M, N, K = T, ff, d
+a = torch.randn(M, K, device="cuda").bfloat16(); bt = torch.randn(N, K, device="cuda").bfloat16(); bias = torch.randn(N, device="cuda")
+fl = 2.0 * M * N * K
+t1 = timeit(lambda: ops.gemm_nt(a, bt, bias, None, "gelu", 0.1, 7))
+def unfused():
+    u = torch.mm(a, bt.t()); return ops.bias_act_fwd(u, bias, "gelu", 0.1, 7)
+t2 = timeit(unfused)
+print(f"NT mlp1+gelu+dropout: mgx fused {t1*1e3:7.1f} us {fl/t1/1e9:7.1f} TF | torch.mm + bias_act_fwd {t2*1e3:7.1f} us")
