@@ -351,6 +351,21 @@ import os as _os
 # training shapes (tools/gemm_bench.py): the MLP up-projection with its fused bias+GELU+dropout epilogue
 # and every weight gradient (TN, split-K, fp32 output) run on libmgx, the rest on the library.
 GEMM_BACKEND = _os.environ.get("MGX_GEMM", "auto")
+# Operand orientation handed to the library for the projections it runs: "nt" = weight as [N, K] (K contiguous,
+# the transposed shadow where the master is stored [K, N]); "nn" = weight as [K, N]; "native" = whichever
+# orientation the master parameter has.  Measured in the training step on MI355X (hipBLASLt picks a different
+# kernel family per orientation): nt 1.27-1.40 PF vs nn 1.07-1.29 PF at these shapes.
+LIB_LAYOUT = _os.environ.get("MGX_LIB_LAYOUT", "nt")
+
+
+def _pick(native_is_kn, kn, nk):
+    """[K, N]-shaped weight operand for a library GEMM in the configured storage orientation.
+    kn() -> the copy stored [K, N]; nk() -> the copy stored [N, K] (callables: only one is materialised)."""
+    if LIB_LAYOUT == "nt" or (LIB_LAYOUT == "native" and not native_is_kn):
+        return nk().t()
+    return kn()
+
+
 _AUTO_SITES = {"mlp1", "dwp", "dw1", "dw2", "dwqkv"}
 
 
@@ -387,20 +402,22 @@ class _DecoderBlock(torch.autograd.Function):
         if "qkv" in mgx:
             qkv = gemm_nt(x2, W.wqkv_t, W.m_bqkv).view(B, S, 3 * d)
         else:
-            qkv = torch.addmm(W.bqkv, x2, W.wqkv).view(B, S, 3 * d)
+            qkv = torch.addmm(W.bqkv, x2, _pick(True, lambda: W.wqkv, lambda: W.wqkv_t)).view(B, S, 3 * d)
         if E is None:
             a, lse = alibi_attn_fwd(qkv, slopes, n_heads)
         else:
             a, lse = rel_attn_fwd(qkv, E, n_heads)
         a2 = a.view(T, d)
-        pr = gemm_nt(a2, W.wp_t, W.m_bp) if "proj" in mgx else torch.addmm(W.bp, a2, W.wp)
+        pr = (gemm_nt(a2, W.wp_t, W.m_bp) if "proj" in mgx
+              else torch.addmm(W.bp, a2, _pick(True, lambda: W.wp, lambda: W.wp_t)))
         h1, z1, mean1, rstd1 = ln_residual_fwd(pr, x2, W.m_g1, W.m_be1, eps, p, seed1)
         if "mlp1" in mgx:
             pre, hact = gemm_nt(h1, W.w1, W.m_b1, None, act, p, seed2)
         else:
-            u = torch.mm(h1, W.w1.t())
+            u = torch.mm(h1, _pick(False, lambda: W.w1_t, lambda: W.w1))
             pre, hact = bias_act_fwd(u, W.m_b1, act, p, seed2)
-        v = gemm_nt(hact, W.w2, W.m_b2) if "mlp2" in mgx else torch.addmm(W.b2, hact, W.w2.t())
+        v = (gemm_nt(hact, W.w2, W.m_b2) if "mlp2" in mgx
+             else torch.addmm(W.b2, hact, _pick(False, lambda: W.w2_t, lambda: W.w2)))
         h2, z2, mean2, rstd2 = ln_residual_fwd(v, h1, W.m_g2, W.m_be2, eps)
         ctx.save_for_backward(x2, qkv, a, lse, z1, mean1, rstd1, h1, pre, hact, z2, mean2, rstd2, slopes, E)
         ctx.W = W
@@ -417,14 +434,17 @@ class _DecoderBlock(torch.autograd.Function):
         dh2 = dh2.reshape(T, d).contiguous()
         dz2, _, dg2, dbe2, db2 = ln_residual_bwd(dh2, None, z2, mean2, rstd2, W.m_g2, want_dsum=True)
         dw2 = gemm_tn(dz2, hact) if "dw2" in mgx else torch.mm(dz2.t(), hact)          # [d, ff]
-        dact = gemm_nt(dz2, W.w2_t) if "dact" in mgx else torch.mm(dz2, W.w2)           # [T, ff]
+        dact = (gemm_nt(dz2, W.w2_t) if "dact" in mgx
+                else torch.mm(dz2, _pick(True, lambda: W.w2, lambda: W.w2_t)))          # [T, ff]
         dpre, db1 = bias_act_bwd(dact, pre, act, p, seed2)
         dw1 = gemm_tn(dpre, h1) if "dw1" in mgx else torch.mm(dpre.t(), h1)             # [ff, d]
-        dh1 = gemm_nt(dpre, W.w1_t) if "dh1" in mgx else torch.mm(dpre, W.w1)           # [T, d]
+        dh1 = (gemm_nt(dpre, W.w1_t) if "dh1" in mgx
+               else torch.mm(dpre, _pick(True, lambda: W.w1, lambda: W.w1_t)))          # [T, d]
         dz1, da1, dg1, dbe1, dbp = ln_residual_bwd(dh1, dz2, z1, mean1, rstd1, W.m_g1, p, seed1, want_dsum=True)
         a2 = a.view(T, d)
         dwp = gemm_tn(a2, da1) if "dwp" in mgx else torch.mm(a2.t(), da1)               # [d, d]
-        da = (gemm_nt(da1, W.wp) if "da" in mgx else torch.mm(da1, W.wp.t())).view(B, S, d)   # da1 @ wp^T
+        da = (gemm_nt(da1, W.wp) if "da" in mgx
+              else torch.mm(da1, _pick(False, lambda: W.wp_t, lambda: W.wp))).view(B, S, d)   # da1 @ wp^T
         if E is None:
             dqkv = alibi_attn_bwd(da, qkv, a, lse, slopes, n_heads)
             dE = None
@@ -436,7 +456,7 @@ class _DecoderBlock(torch.autograd.Function):
         if "dx" in mgx:
             dx = gemm_nt(dqkv2, W.wqkv, None, dz1).view(B, S, d)                        # dqkv @ wqkv^T + dz1
         else:
-            dx = torch.addmm(dz1, dqkv2, W.wqkv.t()).view(B, S, d)
+            dx = torch.addmm(dz1, dqkv2, _pick(False, lambda: W.wqkv_t, lambda: W.wqkv)).view(B, S, d)
         return (dx, None, None, dE, None, None,
                 dwqkv.unsqueeze(0), dbqkv, dwp.unsqueeze(0), dbp, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2)
 
