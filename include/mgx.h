@@ -170,6 +170,12 @@ int mgx_adamw(float* param, const void* grad, float* exp_avg, float* exp_avg_sq,
               long n, float lr, float beta1, float beta2, float eps, float weight_decay,
               int step, float grad_scale, int grad_dtype, void* stream);
 
+/* Multi-tensor form of mgx_adamw (fp32 gradients, no shadow): `count` tensors, HOST arrays of device
+ * pointers and element counts; one launch per 32 tensors.  Same arithmetic, element by element. */
+int mgx_adamw_multi(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const long* sizes, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int step, float grad_scale, void* stream);
+
 /* ---- bf16 MFMA GEMMs for the projections ----------------------------------------------------
  * Replace Conv1d.forward (base_layers.py:54-57) and nn.Linear (alibi_unified.py:90,92) and their
  * autograd GEMMs.  Tile 256x256x64, fp32 accumulate.

@@ -449,6 +449,66 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// Multi-tensor form: one launch updates up to ADAM_MAX tensors (their pointers travel in the kernel
+// arguments); block b works on a 4096-element chunk of the tensor whose block range contains b.
+constexpr int ADAM_MAX = 32, ADAM_CHUNK = 4096;
+struct AdamMulti {
+    float* p[ADAM_MAX];
+    const float* g[ADAM_MAX];
+    float* m[ADAM_MAX];
+    float* v[ADAM_MAX];
+    long n[ADAM_MAX];
+    int bstart[ADAM_MAX + 1];
+    int count;
+};
+__device__ __forceinline__ float adamw_one(float w, float gr, float& m, float& v, float lr, float b1, float b2,
+                                            float eps, float wd, float bc1, float bc2_sqrt) {
+    w -= lr * wd * w;
+    m = b1 * m + (1.f - b1) * gr;
+    v = b2 * v + (1.f - b2) * gr * gr;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    return w - (lr / bc1) * (m / denom);
+}
+__global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMulti a, float lr, float b1, float b2, float eps,
+                                                           float wd, float bc1, float bc2_sqrt, float gscale) {
+    int t = 0;
+    while (t + 1 < a.count && (int)blockIdx.x >= a.bstart[t + 1]) ++t;          // block-uniform
+    const long n = a.n[t];
+    const long base = (long)((int)blockIdx.x - a.bstart[t]) * ADAM_CHUNK;
+    float* __restrict__ p = a.p[t];
+    const float* __restrict__ g = a.g[t];
+    float* __restrict__ m = a.m[t];
+    float* __restrict__ v = a.v[t];
+    const bool vec = (n & 3) == 0;                                               // 16-byte rows (tensors are 256-B aligned)
+#pragma unroll
+    for (int q = 0; q < ADAM_CHUNK / 1024; ++q) {
+        const long i = base + q * 1024 + threadIdx.x * 4;
+        if (vec && i + 4 <= n) {
+            f32x4 w4 = *reinterpret_cast<const f32x4*>(p + i);
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + i);
+            f32x4 m4 = *reinterpret_cast<const f32x4*>(m + i);
+            f32x4 v4 = *reinterpret_cast<const f32x4*>(v + i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float mm = m4[k], vv = v4[k];
+                w4[k] = adamw_one(w4[k], g4[k] * gscale, mm, vv, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+                m4[k] = mm;
+                v4[k] = vv;
+            }
+            *reinterpret_cast<f32x4*>(p + i) = w4;
+            *reinterpret_cast<f32x4*>(m + i) = m4;
+            *reinterpret_cast<f32x4*>(v + i) = v4;
+        } else {
+            for (long e = i; e < min(i + 4, n); ++e) {
+                float mm = m[e], vv = v[e];
+                p[e] = adamw_one(p[e], g[e] * gscale, mm, vv, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+                m[e] = mm;
+                v[e] = vv;
+            }
+        }
+    }
+}
+
 template <typename T>
 int ln_fwd_launch(const void* a, const void* res, const float* gamma, const float* beta, void* y, void* z,
                   float* mean, float* rstd, long T_rows, int d, float eps, float p, unsigned long long seed,
@@ -583,5 +643,41 @@ extern "C" int mgx_adamw(float* param, const void* grad, float* exp_avg, float* 
                            exp_avg, exp_avg_sq, (bf16_t*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
                            grad_scale);
     MGX_CHECK_LAUNCH("adamw");
+    return MGX_OK;
+}
+
+extern "C" int mgx_adamw_multi(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                               float* const* exp_avg_sq, const long* sizes, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    MGX_REQUIRE(count > 0 && params && grads && exp_avg && exp_avg_sq && sizes, MGX_EINVAL,
+                "mgx_adamw_multi: null pointer or count=%d", count);
+    MGX_REQUIRE(step >= 1, MGX_EINVAL, "mgx_adamw_multi: step=%d", step);
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipStream_t st = (hipStream_t)stream;
+    for (int t0 = 0; t0 < count; t0 += ADAM_MAX) {
+        AdamMulti a;
+        a.count = count - t0 < ADAM_MAX ? count - t0 : ADAM_MAX;
+        long blocks = 0;
+        for (int i = 0; i < a.count; ++i) {
+            const int t = t0 + i;
+            MGX_REQUIRE(params[t] && grads[t] && exp_avg[t] && exp_avg_sq[t] && sizes[t] > 0, MGX_EINVAL,
+                        "mgx_adamw_multi: tensor %d: null pointer or empty", t);
+            MGX_REQUIRE(((uintptr_t)params[t] | (uintptr_t)grads[t] | (uintptr_t)exp_avg[t] | (uintptr_t)exp_avg_sq[t]) % 16 == 0,
+                        MGX_EUNSUPPORTED, "mgx_adamw_multi: tensor %d is not 16-byte aligned", t);
+            a.p[i] = params[t];
+            a.g[i] = grads[t];
+            a.m[i] = exp_avg[t];
+            a.v[i] = exp_avg_sq[t];
+            a.n[i] = sizes[t];
+            a.bstart[i] = (int)blocks;
+            blocks += (sizes[t] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+            MGX_REQUIRE(blocks < (1L << 30), MGX_EUNSUPPORTED, "mgx_adamw_multi: too many elements in one launch");
+        }
+        a.bstart[a.count] = (int)blocks;
+        hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, lr, beta1, beta2, eps,
+                           weight_decay, bc1, bc2s, grad_scale);
+        MGX_CHECK_LAUNCH("adamw_multi");
+    }
     return MGX_OK;
 }

@@ -557,3 +557,22 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, 
             raise ValueError("shadow size mismatch")
     check(lib.mgx_adamw(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(shadow), n, lr, beta1, beta2, eps,
                         weight_decay, step, grad_scale, _dt(grad), _stream()), "mgx_adamw")
+
+
+def adamw_step_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """One fused AdamW update over a list of fp32 tensors (mgx_adamw_multi): 1 launch per 32 tensors."""
+    import ctypes as C
+    n = len(params)
+    if not (len(grads) == len(exp_avgs) == len(exp_avg_sqs) == n) or n == 0:
+        raise ValueError("adamw_step_multi: list lengths differ or are empty")
+    for p, g, m, v in zip(params, grads, exp_avgs, exp_avg_sqs):
+        _need(p, "param", torch.float32)
+        _need(g, "grad", torch.float32)
+        _need(m, "exp_avg", torch.float32)
+        _need(v, "exp_avg_sq", torch.float32)
+        if not (g.numel() == m.numel() == v.numel() == p.numel()):
+            raise ValueError("adamw_step_multi: size mismatch")
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    sizes = (C.c_long * n)(*[p.numel() for p in params])
+    check(lib.mgx_adamw_multi(n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), sizes, lr, beta1, beta2, eps,
+                              weight_decay, step, grad_scale, _stream()), "mgx_adamw_multi")

@@ -22,6 +22,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 loss = closure()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            batch = {}                                   # step count -> ([p], [g], [m], [v]) for the multi-tensor launch
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -32,6 +33,19 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                ops.adamw_step(p, g, st["exp_avg"], st["exp_avg_sq"], None, float(group["lr"]), b1, b2, group["eps"],
-                               group["weight_decay"], int(st["step"]))
+                if g.dtype == torch.float32 and p.is_contiguous():
+                    lists = batch.setdefault(int(st["step"]), ([], [], [], []))
+                    for lst, t in zip(lists, (p, g, st["exp_avg"], st["exp_avg_sq"])):
+                        lst.append(t)
+                else:
+                    ops.adamw_step(p, g, st["exp_avg"], st["exp_avg_sq"], None, float(group["lr"]), b1, b2,
+                                   group["eps"], group["weight_decay"], int(st["step"]))
+            for step, (ps, gs, ms, vs) in batch.items():
+                ops.adamw_step_multi(ps, gs, ms, vs, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
+                                     step)
+            # the kernels wrote the parameters behind autograd's back: advance their version counters so that
+            # everything keyed on them (the models' compute-dtype weight shadows, saved-tensor checks) sees the update
+            for p in group["params"]:
+                if p.grad is not None:
+                    torch.autograd.graph.increment_version(p)
         return loss

@@ -405,6 +405,28 @@ def test_adamw_matches_torch():
     assert torch.equal(shadow, p.bfloat16())
 
 
+def test_adamw_multi_matches_torch():
+    """Multi-tensor launch (mgx_adamw_multi): ragged sizes incl. one that is not a multiple of 4 and more
+    tensors than one launch holds; three steps against torch.optim.AdamW."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(10)
+    sizes = [618, 1000, 4096 * 3 + 4, 7, 1024 * 1024] + [64 + 4 * i for i in range(35)]
+    p0 = [torch.randn(n, generator=g) for n in sizes]
+    refs = [t.clone().requires_grad_(True) for t in p0]
+    opt = torch.optim.AdamW(refs, lr=1e-3, weight_decay=1e-4)
+    ps = [t.clone().cuda() for t in p0]
+    ms = [torch.zeros_like(t) for t in ps]
+    vs = [torch.zeros_like(t) for t in ps]
+    for step in range(1, 4):
+        grads = [torch.randn(n, generator=g) for n in sizes]
+        for r, gr in zip(refs, grads):
+            r.grad = gr.clone()
+        opt.step()
+        ops.adamw_step_multi(ps, [gr.cuda() for gr in grads], ms, vs, 1e-3, 0.9, 0.999, 1e-8, 1e-4, step)
+    for p, r in zip(ps, refs):
+        assert float((p.cpu() - r.detach()).abs().max()) < 1e-6
+
+
 def test_bad_arguments_fail_loudly():
     ops = _ops()
     from musicgeneration_amd._lib import MgxError
