@@ -30,6 +30,18 @@ PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0         # HBM3E spec, same table
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch of a roofline kernel from the committed TCC-counter passes (tools/traffic.sh:
+    FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs, read side doubled as MI355X_MICROARCH.md's HBM
+    section prescribes for gfx950).  None when no measurement exists for this exact kernel configuration."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as f:
+            t = json.load(f)
+        return float(t[key]["hbm_bytes_corrected"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def fwd_flops_per_token(L, d, ff, S, V, s_eff_factor=1.0):
     """L*(2d*3d + 2d*d + 4d*ff + 2d*S_eff) + 2dV, causal attention at half the square."""
     return L * (2 * d * 3 * d + 2 * d * d + 4 * d * ff + 2 * d * S * s_eff_factor) + 2 * d * V
@@ -175,16 +187,21 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.KERNEL_EVENTS = {}                             # HIP-event pairs around the roofline kernel's launches
+    # HIP-event pairs around the hand-written MFMA kernels' launches, inside the timed region, on the first
+    # EVENT_STEPS steps only (84 event records per step cost ~0.2 ms of the step they bracket)
+    EVENT_STEPS = min(3, a.steps)
+    events = ops.KERNEL_EVENTS = {}
     t0 = time.perf_counter()
     for i in range(a.steps):
+        if i == EVENT_STEPS:
+            ops.KERNEL_EVENTS = None
         loss = step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    ops.KERNEL_EVENTS = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -194,17 +211,31 @@ def main():
     tokens = world * B * S * a.steps
     value = tokens / dt
     train_fl = 3 * fwd_fl
-    # roofline: attention forward kernel (one launch per layer per step)
-    roof = None
-    ev = events.get("alibi_attn_fwd") or events.get("rel_attn_fwd")
-    if ev:
-        ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
-        factor = 1.5 if a.workload == "train_relative" else 1.0
-        fl = 2.0 * B * H * S * S * dh * factor               # causal-algorithmic: QK^T + PV (+ QE^T) at half the square
-        ach = fl / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "attention forward (libmgx flash kernel)", "achieved": ach,
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
-                "launches_timed": len(ev), "avg_launch_ms": ms, "flops_per_launch": fl}
+    # roofline: every hand-written MFMA kernel that is timed by a HIP-event pair around its launches inside the
+    # timed region (musicgeneration_amd.ops._timed, on the stream the kernels run on); the headline `roofline`
+    # object is the one with the largest total time.  achieved = algorithmic FLOPs of the launches / their time.
+    labels = {"alibi_attn_fwd": "attn_fwd_mfma_kernel (ALiBi flash forward; QK^T + PV at half the square)",
+              "rel_attn_fwd": "rel_fwd_mfma_kernel (skew relative flash forward; QK^T + QE^T + PV at half the square)",
+              "alibi_attn_bwd": "attn_bwd_dkv_mfma_kernel + attn_bwd_dq_mfma_kernel + delta (5 products at half the square)",
+              "gemm_nt": "gemm_nt_kernel (MLP up-projection with bias + GELU + dropout epilogue)",
+              "gemm_tn": "gemm_tn_kernel + splitk_reduce_kernel (weight gradients, split-K fp32 slabs)"}
+    lines = []
+    for name, ev in events.items():
+        if name not in labels or not ev:
+            continue
+        tot_ms = sum(s.elapsed_time(e) for s, e, _ in ev)
+        fl = sum(w for _, _, w in ev)
+        ach = fl / (tot_ms * 1e-3) / 1e12
+        traffic = None
+        if name == "alibi_attn_fwd" and a.workload == "train_unified" and (B, S, H, dh) == (16, 2048, 8, 128):
+            traffic = pmc_traffic("attn_fwd_mfma_kernel<128,8> B16 S2048 H8")
+        lines.append({"bound": "mfma", "kernel": labels[name], "achieved": ach, "peak": PEAK_BF16_TFLOPS,
+                      "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                      "traffic_unit": "HBM bytes per launch (TCC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic_pmc.json)",
+                      "launches_timed": len(ev), "avg_launch_ms": tot_ms / len(ev), "flops_per_launch": fl / len(ev),
+                      "ms_per_step": tot_ms / EVENT_STEPS})
+    lines.sort(key=lambda r: -r["ms_per_step"])
+    roof = lines[0] if lines else None
     out = {
         "metric": "training tokens/sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -214,6 +245,7 @@ def main():
         "step_tflops": value * train_fl / 1e12, "step_frac_of_bf16_peak": value * train_fl / 1e12 / PEAK_BF16_TFLOPS / world,
         "final_loss": final_loss,
         "roofline": roof,
+        "roofline_other_kernels": lines[1:],
     }
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
@@ -272,12 +304,16 @@ def bench_decode(a, device, rank, world):
     ev = events.get("decode_attn")
     roof = None
     if ev:
-        ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
+        ms = sum(s.elapsed_time(e) for s, e, _ in ev) / len(ev)
         mean_ctx = 64 + steps / 2
         by = B * 2 * d * mean_ctx * esz                     # K and V rows of one layer, mean context
         ach = by / (ms * 1e-3) / 1e9
+        traffic = pmc_traffic("decode_attn_bf16_kernel B64 H8 dh128 R3 ctx2112") if (B, steps, a.dtype) == (64, 4096, "bf16") else None
         roof = {"bound": "hbm", "kernel": "decode_attn_kernel", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": ach / PEAK_HBM_GBS, "traffic": None, "launches_timed": len(ev), "avg_launch_ms": ms,
+                "frac": ach / PEAK_HBM_GBS, "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch at the mean context 2112 (TCC FETCH_SIZE x2 + WRITE_SIZE, "
+                                "profiles/r01_traffic_pmc.json)",
+                "launches_timed": len(ev), "avg_launch_ms": ms,
                 "bytes_per_launch": by, "timed_in": "launch-by-launch pass of the same continuation",
                 "launch_by_launch_tokens_per_s": B * steps / dt_eager, "graph_tokens_equal": same}
     out = {"metric": "decode tokens/sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": 16,

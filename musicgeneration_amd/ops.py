@@ -52,8 +52,9 @@ KERNEL_EVENTS = None
 class _timed:
     """Records a HIP-event pair on the current stream around one kernel launch when KERNEL_EVENTS is a dict."""
 
-    def __init__(self, name):
+    def __init__(self, name, work=0.0):
         self.name = name
+        self.work = work          # algorithmic FLOPs (or bytes) of this launch, for bench.py's roofline lines
 
     def __enter__(self):
         if KERNEL_EVENTS is not None:
@@ -65,7 +66,7 @@ class _timed:
     def __exit__(self, *a):
         if KERNEL_EVENTS is not None:
             self.e.record()
-            KERNEL_EVENTS.setdefault(self.name, []).append((self.s, self.e))
+            KERNEL_EVENTS.setdefault(self.name, []).append((self.s, self.e, self.work))
         return False
 
 
@@ -87,7 +88,7 @@ def alibi_attn_fwd(qkv: torch.Tensor, slopes: torch.Tensor, n_heads: int) -> Tup
         raise ValueError(f"bad attention shapes qkv={tuple(qkv.shape)} heads={n_heads} slopes={slopes.numel()}")
     out = torch.empty(B, S, d, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, n_heads, S, dtype=torch.float32, device=qkv.device)
-    with _timed("alibi_attn_fwd"):
+    with _timed("alibi_attn_fwd", 2.0 * B * n_heads * S * S * (d // n_heads)):
         check(lib.mgx_alibi_attn_fwd(_p(qkv), _p(slopes), _p(out), _p(lse), B, S, n_heads, d // n_heads, _dt(qkv),
                                      _stream()), "mgx_alibi_attn_fwd")
     return out, lse
@@ -101,8 +102,9 @@ def alibi_attn_bwd(dout, qkv, out, lse, slopes, n_heads: int) -> torch.Tensor:
         raise ValueError("bad attention backward shapes")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
-    check(lib.mgx_alibi_attn_bwd(_p(dout), _p(qkv), _p(out), _p(lse), _p(slopes), _p(dqkv), _p(delta), B, S, n_heads,
-                                 d // n_heads, _dt(qkv), _stream()), "mgx_alibi_attn_bwd")
+    with _timed("alibi_attn_bwd", 5.0 * B * n_heads * S * S * (d // n_heads)):      # 5 products at half the square
+        check(lib.mgx_alibi_attn_bwd(_p(dout), _p(qkv), _p(out), _p(lse), _p(slopes), _p(dqkv), _p(delta), B, S, n_heads,
+                                     d // n_heads, _dt(qkv), _stream()), "mgx_alibi_attn_bwd")
     return dqkv
 
 
@@ -116,7 +118,7 @@ def rel_attn_fwd(qkv: torch.Tensor, E: torch.Tensor, n_heads: int):
         raise ValueError(f"bad relative attention shapes qkv={tuple(qkv.shape)} E={tuple(E.shape)}")
     out = torch.empty(B, S, d, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, S, dtype=torch.float32, device=qkv.device)
-    with _timed("rel_attn_fwd"):
+    with _timed("rel_attn_fwd", 3.0 * B * H * S * S * dh):
         check(lib.mgx_rel_attn_fwd(_p(qkv), _p(E), _p(out), _p(lse), B, S, H, dh, M, _dt(qkv), _stream()),
               "mgx_rel_attn_fwd")
     return out, lse
@@ -245,7 +247,7 @@ def gemm_nt(a, bt, bias=None, res=None, act=None, p_drop=0.0, seed=0, n_pad_to=8
             raise ValueError("gemm_nt: residual shape")
     c = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
     c2 = torch.empty_like(c) if act is not None else None
-    with _timed("gemm_nt"):
+    with _timed("gemm_nt", 2.0 * M * N * K):
         check(lib.mgx_gemm_nt_bf16(_p(a), _p(bt), _p(c), _p(c2), _p(bias), _p(res), M, N, K, K, K, N,
                                    -1 if act is None else _ACT[act], float(p_drop), seed, _stream()), "mgx_gemm_nt_bf16")
     return c if act is None else (c, c2)
@@ -262,7 +264,7 @@ def gemm_tn(a, b, out_dtype=torch.float32):
     ws_n = lib.mgx_gemm_tn_workspace_floats(M, N, K, None)
     ws = torch.empty(ws_n, dtype=torch.float32, device=a.device)
     c = torch.empty(M, N, dtype=out_dtype, device=a.device)
-    with _timed("gemm_tn"):
+    with _timed("gemm_tn", 2.0 * M * N * K):
         check(lib.mgx_gemm_tn_bf16(_p(a), _p(b), _p(c), _p(ws), M, N, K, M, N, _dt(c), _stream()), "mgx_gemm_tn_bf16")
     return c
 
