@@ -15,6 +15,8 @@
 // epilogue goes through LDS so that C is written in full 512-byte row segments with 16-byte stores,
 // with bias / residual / GELU / dropout applied on the way.  Workgroup ids are remapped so that each
 // XCD works on a compact set of tiles that share operand panels (L2 reuse).
+// The TN kernel stays on v_mfma_f32_32x32x16_bf16: on 16x16x32 it was no faster (data-movement bound) and
+// its transposed-read addressing cost three spilled registers.
 #include "mgx_common.h"
 
 namespace {
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs g) {
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, h5 = lane >> 5;
     const int wm = w >> 2, wn = w & 3;
     const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM;
     const int ntile = nbm * nbn;
@@ -369,26 +372,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmArgs g) {
         for (int i = 0; i < 4; ++i) stage_piece(k0, buf, i);
     };
 
-    // Transposed reads for the 16x16x32 operand: lane l holds column (l & 15) of a 16-column block and
-    // k = 8 * (l >> 4) .. +7 of a 32-deep step = two ds_read_b64_tr_b16 of 4 k rows each.  In a 16-lane group
-    // lane 4*qq + p supplies the address of k row qq (+4 for the second read), columns 4p .. 4p+3.
-    const int l15 = lane & 15, g4 = lane >> 4;
-    const int qq = l15 >> 2, p = lane & 3;
-    int t1[2], t2[2];                                   // by parity of the 16-column block (chunk pair 0-1 / 2-3)
-#pragma unroll
-    for (int cp = 0; cp < 2; ++cp) {
-        t1[cp] = 2048 * g4 + 64 * qq + 16 * ((2 * cp + (p >> 1)) ^ ((2 * g4) & 3)) + 8 * (p & 1);
-        t2[cp] = 2048 * g4 + 64 * (qq + 4) + 16 * ((2 * cp + (p >> 1)) ^ ((2 * g4 + 1) & 3)) + 8 * (p & 1);
-    }
-    // wave's columns: A image half wm (128 m columns = 8 blocks of 16), B columns 64*wn .. +64 (4 blocks)
+    // transposed-read lane offsets (see attn_mfma.hip LaneAddr): columns on the lanes, k reduced
+    const int q = (lane & 15) >> 2, p = lane & 3, g1 = (lane >> 4) & 1;
+    const int x = 2 * g1 + (p >> 1);
+    const int rbase = 64 * (4 * h5 + q) + 8 * (p & 1);
+    const int tr0 = rbase + 16 * (x ^ h5), tr1 = rbase + 16 * ((x ^ h5) ^ 2);
+    // wave's columns: A image half wm (128 m columns = 4 blocks of 32), B columns 64*wn .. +64
     const int a_base = wm * (TILE_BYTES / 2);
     const int b_base = TILE_BYTES + (wn >> 1) * (TILE_BYTES / 2) + 512 * (2 * (wn & 1));
 
-    f32x4 acc[8][4];
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // Main loop: same two-group schedule as gemm_nt_kernel (waves 0-3 and 4-7 run one interval apart:
     // one group reads every fragment of its K tile into registers while the other issues 32 MFMAs);
@@ -407,16 +406,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
         const char* s = smem + (kt & 1) * STAGE_BYTES;
         // ---- READ interval
-        bf16x8 bf[2][4], af[2][8];
+        bf16x8 bf[4][2], af[4][4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {                      // 32 k per step: 8-row groups 4ks .. 4ks+3 (one per lane group)
-            const int ko = 8192 * ks;
+        for (int ks = 0; ks < 4; ++ks) {                      // 16 k per step: 8-row groups 2ks, 2ks+1
+            const int k0o = 2048 * (2 * ks), k1o = 2048 * (2 * ks + 1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                bf[ks][j] = lds_tr_pair(s + b_base + 512 * (j >> 1) + t1[j & 1] + ko, s + b_base + 512 * (j >> 1) + t2[j & 1] + ko);
+            for (int j = 0; j < 2; ++j)
+                bf[ks][j] = lds_tr_pair(s + b_base + 512 * j + tr0 + k0o, s + b_base + 512 * j + tr1 + k1o);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                af[ks][i] = lds_tr_pair(s + a_base + 512 * (i >> 1) + t1[i & 1] + ko, s + a_base + 512 * (i >> 1) + t2[i & 1] + ko);
+            for (int i = 0; i < 4; ++i)
+                af[ks][i] = lds_tr_pair(s + a_base + 512 * i + tr0 + k0o, s + a_base + 512 * i + tr1 + k1o);
         }
         if (grp == 0 && kt + 1 < nk) stage(kbeg + (kt + 1) * BK, (kt + 1) & 1);
         if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -428,16 +427,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmArgs g) {
         const bool g1stage = grp == 1 && kt + 2 < nk;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {                          // quarter of the K tile's MFMAs: step q >> 1, M blocks 4*(q&1)..
-            const int ks = q >> 1;
+        for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = 4 * (q & 1) + ii;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
-                }
-            if (g1stage) stage_piece(kbeg + (kt + 2) * BK, kt & 1, q);
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+            if (g1stage) stage_piece(kbeg + (kt + 2) * BK, kt & 1, ks);
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
@@ -450,20 +446,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(GemmArgs g) {
     // fp32 slab store: D[row = n][col = m]: lane = m, 4 consecutive n per register group (16-B stores)
     float* C = reinterpret_cast<float*>(g.C) + (long)split * g.M * g.ldc;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + 128 * wm + 16 * i + l15;
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 128 * wm + 32 * i + l31;
         if (m >= g.M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + 64 * wn + 16 * j + 4 * g4;
-            if (n + 4 <= g.N) {
-                *reinterpret_cast<f32x4*>(C + (long)m * g.ldc + n) = acc[i][j];
-            } else {
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (n + k < g.N) C[(long)m * g.ldc + n + k] = acc[i][j][k];
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = n0 + 64 * wn + 32 * j + 8 * gq + 4 * h5;
+                if (n + 4 <= g.N) {
+                    f32x4 v = {acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
+                    *reinterpret_cast<f32x4*>(C + (long)m * g.ldc + n) = v;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (n + k < g.N) C[(long)m * g.ldc + n + k] = acc[i][j][4 * gq + k];
+                }
             }
-        }
     }
 }
 
