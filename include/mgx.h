@@ -194,6 +194,25 @@ long mgx_gemm_tn_workspace_floats(int M, int N, int K, int* splits_out);
 int mgx_gemm_tn_bf16(const void* A, const void* B, void* C, float* workspace, int M, int N, int K,
                      int lda, int ldb, int out_dtype, void* stream);
 
+/* ---- unified MIDI token codec (the step either side of the model) ---------------------------------
+ * Decode replaces UnifiedReconstruct.reconstruct_stream (data/transforms.py:339-365) with unflatten_notes_
+ * (transforms.py:94-128) and the running time of stream_to_raw_stream_ (data/parse_midi_numba.py:196-204):
+ *   tokens [B,L] int32 (sampled rows, BOS 0 / EOS-pad 1 handled as the reference does)
+ *   dur_ticks [duration_bins] int32 = (bin_arr[d] * ticks) truncated, computed once on the host in float64
+ *   events [B,L,3] int32: rows 0..counts[b]-1 = (note 0..87 or -1 for a time shift, velocity, duration in ticks)
+ *   abs_time [B,L] int32: absolute tick at which event k starts (sum of the time shifts before it)
+ *   counts [B] int32: number of events; -1 when the row has no note-class token (the reference raises IndexError)
+ * Encode replaces flatten_notes (transforms.py:11-38), the window of transforms.py:172-176 (its random start is
+ * the `starts` argument) and UnifiedEncoding.pad (transforms.py:149-152):
+ *   notes / velocities / durations [B,Nmax] int32 (note 0 = time shift; durations already binned), lengths [B],
+ *   starts [B] -> tokens [B,seq_len] int32.
+ * Integer work, bit-exact. */
+int mgx_unified_decode_events(const int* tokens, int B, int L, const int* dur_ticks, int note_bins, int velocity_bins,
+                              int duration_bins, int* events, int* abs_time, int* counts, void* stream);
+int mgx_unified_encode_tokens(const int* notes, const int* velocities, const int* durations, const int* lengths,
+                              const int* starts, int B, int Nmax, int seq_len, int note_bins, int velocity_bins,
+                              int duration_bins, int* tokens, void* stream);
+
 /* Test hook (no reference counterpart): route attention through the generic
  * kernels (on != 0) or restore the MFMA dispatch (on == 0). */
 void mgx_debug_force_generic_attention(int on);

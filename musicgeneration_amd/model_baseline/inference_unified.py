@@ -13,3 +13,12 @@ except Exception:                       # pragma: no cover
 
 def inference(self, seq, idx=1, deterministic=False):
     return sample_next_plus_one(self, seq, idx=idx, deterministic=deterministic, progress=tqdm)
+
+
+def reconstruct(seq, ticks: int = 480):
+    """What inference_unified.py:51-55 does after sampling, without the numba / py_midicsv stack: the sampled
+    buffer [B,L] (GPU) -> one RawMidiStream per row (note-on / note-off events sorted by time, ready for a MIDI
+    writer) through the device token codec (musicgeneration_amd.codec).  The caller sets
+    seq[:, -1] = 1 (EOS) first, as the reference script does."""
+    from ..codec import UnifiedReconstruct
+    return UnifiedReconstruct(ticks=ticks).raw_streams(seq)

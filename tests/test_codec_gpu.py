@@ -1,0 +1,90 @@
+"""Device token codec (libmgx) vs the reference's golden vectors and the numpy oracle: bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import token_codec as C
+
+pytestmark = pytest.mark.gpu
+Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "codec_unified.npz"))
+
+
+def _rc():
+    from musicgeneration_amd.codec import UnifiedReconstruct
+    return UnifiedReconstruct()
+
+
+def test_decode_golden_rows_batched():
+    """All golden rows in ONE launch (ragged rows padded with EOS = 1, which the decode cuts at)."""
+    rows = [Z[f"dec{k}.tokens"] for k in range(int(Z["n_dec"]))]
+    for k, row in enumerate(rows):                                   # one by one at their own length
+        s = _rc().reconstruct_stream(row)
+        assert np.array_equal(s.events, Z[f"dec{k}.events"]), k
+    L = max(r.shape[0] for r in rows) + 3
+    pad_ok = [k for k, r in enumerate(rows) if (r == 1).any()]       # padding with 1s changes nothing for these
+    batch = np.ones((len(pad_ok), L), dtype=np.int64)
+    for i, k in enumerate(pad_ok):
+        batch[i, :rows[k].shape[0]] = rows[k]
+    rc = _rc()
+    streams = rc.reconstruct_streams(torch.from_numpy(batch).cuda())
+    raws = rc.raw_streams(torch.from_numpy(batch).cuda())
+    for i, k in enumerate(pad_ok):
+        assert np.array_equal(streams[i].events, Z[f"dec{k}.events"]), k
+        assert np.array_equal(raws[i].events, Z[f"dec{k}.raw"]), k
+
+
+def test_encode_golden():
+    from musicgeneration_amd.codec import encode_unified
+    for k in range(int(Z["n_enc"])):
+        notes, vel, dur = (torch.from_numpy(Z[f"enc{k}.{n}"]).cuda().reshape(1, -1) for n in ("notes", "vel", "dur"))
+        seq_len, start = (int(v) for v in Z[f"enc{k}.meta"])
+        row = encode_unified(notes, vel, dur, torch.tensor([notes.shape[1]]).cuda(), torch.tensor([start]).cuda(), seq_len)
+        assert np.array_equal(row[0].cpu().numpy(), Z[f"enc{k}.row"]), k
+
+
+@pytest.mark.parametrize("L", [5, 64, 1023, 1024, 1025, 4161])
+def test_decode_random_rows_vs_oracle(L):
+    """Generated-like rows at the sampling buffer sizes (chunk boundaries of the 1024-thread scan included)."""
+    rng = np.random.default_rng(L)
+    B = 7
+    tok = rng.integers(2, 618, (B, L))
+    tok[:, 0] = 0
+    tok[1, L // 2:] = 1
+    tok[2, :] = rng.integers(418, 618, L)                            # time shifts only: no note token at all
+    tok[3, 1:] = rng.integers(2, 91, L - 1)                          # notes only: velocity/duration streams stay empty
+    tok[4, -1] = 1
+    rc = _rc()
+    streams = rc.reconstruct_streams(torch.from_numpy(tok).cuda())
+    raws = rc.raw_streams(torch.from_numpy(tok).cuda())
+    for b in range(B):
+        want = C.reconstruct_events(tok[b])
+        if want is None:
+            assert streams[b] is None and raws[b] is None
+            continue
+        assert np.array_equal(streams[b].events, want.reshape(-1, 3)), (L, b)
+        assert np.array_equal(raws[b].events, C.stream_to_raw_events(want.reshape(-1, 3))), (L, b)
+
+
+def test_encode_ragged_batch_vs_oracle_and_round_trip():
+    from musicgeneration_amd.codec import encode_unified
+    rng = np.random.default_rng(3)
+    lens = [1, 40, 1024, 3000, 777]
+    Nmax, seq_len = max(lens), 1024
+    notes = rng.integers(0, 89, (len(lens), Nmax)); vel = rng.integers(1, 127, (len(lens), Nmax))
+    dur = rng.integers(0, 200, (len(lens), Nmax))
+    vel[notes == 0] = 0
+    starts = [0, 0, 311, 2222, 5]
+    rows = encode_unified(*(torch.from_numpy(a).cuda() for a in (notes, vel, dur)), torch.tensor(lens).cuda(),
+                          torch.tensor(starts).cuda(), seq_len).cpu().numpy()
+    for b, n in enumerate(lens):
+        want = C.encode_row(notes[b, :n], vel[b, :n], dur[b, :n], seq_len, starts[b])
+        assert np.array_equal(rows[b], want), b
+    # encode -> decode returns the events of a row that fits (no window, no leading time shift)
+    b = 1
+    first = int(np.argmax(notes[b, :lens[b]] != 0))
+    ev = _rc().reconstruct_stream(rows[b]).events
+    n = lens[b] - first
+    assert np.array_equal(ev[:, 0], notes[b, first:lens[b]] - 1) and ev.shape[0] == n
+    assert np.array_equal(ev[:, 2], C.duration_ticks_table()[dur[b, first:lens[b]]])
