@@ -194,6 +194,15 @@ long mgx_gemm_tn_workspace_floats(int M, int N, int K, int* splits_out);
 int mgx_gemm_tn_bf16(const void* A, const void* B, void* C, float* workspace, int M, int N, int K,
                      int lda, int ldb, int out_dtype, void* stream);
 
+/* ---- rotary position embedding on the packed projection ------------------------------------------
+ * Replaces rotate_every_two / apply_rotary_pos_emb (old_models/rotary_transformer.py:9-21): q and k of
+ * qkv [B,S,3,H,dh] are rotated IN PLACE pair-wise by the angles of cos_tab / sin_tab [S, dh/2] fp32
+ * (FixedPositionalEmbedding, rotary_transformer.py:24-42: sin | cos halves of `emb`).  inverse != 0 applies the
+ * transposed rotation: the backward, applied to dq | dk.  v is untouched.  The attention itself then runs
+ * mgx_alibi_attn_* with zero slopes (plain causal). */
+int mgx_rope_qk(void* qkv, const float* cos_tab, const float* sin_tab, int B, int S, int H, int dh, int inverse,
+                int dtype, void* stream);
+
 /* ---- unified MIDI token codec (the step either side of the model) ---------------------------------
  * Decode replaces UnifiedReconstruct.reconstruct_stream (data/transforms.py:339-365) with unflatten_notes_
  * (transforms.py:94-128) and the running time of stream_to_raw_stream_ (data/parse_midi_numba.py:196-204):

@@ -39,6 +39,7 @@ PROTOTYPES = {
     "mgx_kv_append_at": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "mgx_decode_step_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "mgx_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _i, _vp]),
+    "mgx_rope_qk": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mgx_unified_decode_events": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mgx_unified_encode_tokens": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mgx_adamw_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _f, _vp]),

@@ -136,6 +136,21 @@ def rel_attn_bwd(dout, qkv, out, lse, E, n_heads: int):
     return dqkv, dE
 
 
+def rope_qk_(qkv: torch.Tensor, cos_tab: torch.Tensor, sin_tab: torch.Tensor, n_heads: int, inverse: bool = False):
+    """Rotate q and k of the packed projection qkv [B,S,3*d] in place (rotary_transformer.py:16-21); tables
+    [S, dh/2] fp32.  inverse=True is the backward (applied to dq | dk)."""
+    _need(qkv, "qkv")
+    _need(cos_tab, "cos_tab", torch.float32)
+    _need(sin_tab, "sin_tab", torch.float32)
+    B, S, d3 = qkv.shape
+    dh = d3 // 3 // n_heads
+    if d3 != 3 * n_heads * dh or cos_tab.shape != (S, dh // 2) or sin_tab.shape != (S, dh // 2):
+        raise ValueError(f"rope_qk_: qkv {tuple(qkv.shape)} heads {n_heads} tables {tuple(cos_tab.shape)}")
+    check(lib.mgx_rope_qk(_p(qkv), _p(cos_tab), _p(sin_tab), B, S, n_heads, dh, 1 if inverse else 0, _dt(qkv),
+                          _stream()), "mgx_rope_qk")
+    return qkv
+
+
 # ---------------------------------------------------------------------------
 # (dropout +) residual + LayerNorm
 # ---------------------------------------------------------------------------
@@ -390,7 +405,7 @@ class _DecoderBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cfg, slopes, E_master, E, W, *masters):
-        n_heads, act, p_drop, eps, training = cfg
+        n_heads, act, p_drop, eps, training, rope = cfg
         B, S, d = x.shape
         T = B * S
         x2 = x.reshape(T, d)
@@ -405,6 +420,8 @@ class _DecoderBlock(torch.autograd.Function):
             qkv = gemm_nt(x2, W.wqkv_t, W.m_bqkv).view(B, S, 3 * d)
         else:
             qkv = torch.addmm(W.bqkv, x2, _pick(True, lambda: W.wqkv, lambda: W.wqkv_t)).view(B, S, 3 * d)
+        if rope is not None:                      # rotary variant: rotate q | k in place, then plain causal attention
+            rope_qk_(qkv, rope[0], rope[1], n_heads)
         if E is None:
             a, lse = alibi_attn_fwd(qkv, slopes, n_heads)
         else:
@@ -423,14 +440,14 @@ class _DecoderBlock(torch.autograd.Function):
         h2, z2, mean2, rstd2 = ln_residual_fwd(v, h1, W.m_g2, W.m_be2, eps)
         ctx.save_for_backward(x2, qkv, a, lse, z1, mean1, rstd1, h1, pre, hact, z2, mean2, rstd2, slopes, E)
         ctx.W = W
-        ctx.cfg = (n_heads, act, p, seed1, seed2, B, S, d, mgx)
+        ctx.cfg = (n_heads, act, p, seed1, seed2, B, S, d, mgx, rope)
         return h2.view(B, S, d)
 
     @staticmethod
     def backward(ctx, dh2):
         x2, qkv, a, lse, z1, mean1, rstd1, h1, pre, hact, z2, mean2, rstd2, slopes, E = ctx.saved_tensors
         W = ctx.W
-        n_heads, act, p, seed1, seed2, B, S, d, mgx = ctx.cfg
+        n_heads, act, p, seed1, seed2, B, S, d, mgx, rope = ctx.cfg
         T = B * S
         f32 = torch.float32
         dh2 = dh2.reshape(T, d).contiguous()
@@ -452,6 +469,8 @@ class _DecoderBlock(torch.autograd.Function):
             dE = None
         else:
             dqkv, dE = rel_attn_bwd(da, qkv, a, lse, E, n_heads)
+        if rope is not None:
+            rope_qk_(dqkv, rope[0], rope[1], n_heads, inverse=True)
         dqkv2 = dqkv.view(T, 3 * d)
         dbqkv = dqkv2.sum(0, dtype=f32)
         dwqkv = gemm_tn(x2, dqkv2) if "dwqkv" in mgx else torch.mm(x2.t(), dqkv2)       # [d, 3d]
@@ -463,11 +482,11 @@ class _DecoderBlock(torch.autograd.Function):
                 dwqkv.unsqueeze(0), dbqkv, dwp.unsqueeze(0), dbp, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2)
 
 
-def fused_decoder_block(x, n_heads, act, p_drop, eps, training, slopes, E_master, E, W):
+def fused_decoder_block(x, n_heads, act, p_drop, eps, training, slopes, E_master, E, W, rope=None):
     """W: base_layers.BlockWeights of the block (masters = c_attn.w, c_attn.b, c_proj.w, c_proj.b,
     linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm1.weight, norm1.bias, norm2.weight,
     norm2.bias)."""
-    cfg = (n_heads, act, float(p_drop), float(eps), bool(training))
+    cfg = (n_heads, act, float(p_drop), float(eps), bool(training), rope)       # rope: (cos, sin) [S, dh/2] fp32 or None
     return _DecoderBlock.apply(x, cfg, slopes, E_master, E, W, *W.masters)
 
 

@@ -131,13 +131,33 @@ def relative_attention(q, k, v, E, max_sequence, mask):
 _ACT = {"gelu": F.gelu, "relu": F.relu}
 
 
+def rotary_tables(seq_len: int, dim: int):
+    """FixedPositionalEmbedding (old_models/rotary_transformer.py:24-42): sin | cos of position x inv_freq, fp32.
+    Returns (cos, sin), each [seq_len, dim/2]."""
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim))
+    ang = torch.einsum("i,j->ij", torch.arange(0, seq_len, dtype=torch.float), inv_freq)
+    return ang.cos(), ang.sin()
+
+
+def apply_rotary(t: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
+    """rotate_every_two + apply_rotary_pos_emb (rotary_transformer.py:9-21) on [B,H,S,dh]: pair (2i, 2i+1) of
+    the head dim is rotated by the angle of frequency i (each table entry is repeated for both pair members)."""
+    c = cos.repeat_interleave(2, dim=-1)
+    s = sin.repeat_interleave(2, dim=-1)
+    x1, x2 = t[..., 0::2], t[..., 1::2]
+    rot = torch.stack((-x2, x1), dim=-1).reshape(t.shape)
+    return (t * c) + (rot * s)
+
+
 def decoder_block(sd: StateDict, pre: str, x: Tensor, mask: Tensor, n_heads: int,
-                  activation: str, rel_max_sequence: Optional[int] = None) -> Tensor:
+                  activation: str, rel_max_sequence: Optional[int] = None, rotary=None) -> Tensor:
     """Post-LN block (dropout = identity).  alibi_unified.py:86-95 with
     attention :56-67; relative variant relative_transformer.py:46-58,77-86."""
     d = x.shape[-1]
     c = conv1d(x, sd[pre + "attn.c_attn.w"], sd[pre + "attn.c_attn.b"])
     q, k, v = (_heads(t, n_heads) for t in torch.split(c, d, dim=2))
+    if rotary is not None:
+        q, k = apply_rotary(q, *rotary), apply_rotary(k, *rotary)
     if rel_max_sequence is None:
         a = alibi_attention(q, k, v, mask)
     else:
@@ -153,9 +173,9 @@ def _n_layers(sd: StateDict) -> int:
     return 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("decoder_layers."))
 
 
-def _trunk(sd, h, mask, n_heads, activation, rel_max_sequence=None):
+def _trunk(sd, h, mask, n_heads, activation, rel_max_sequence=None, rotary=None):
     for i in range(_n_layers(sd)):
-        h = decoder_block(sd, f"decoder_layers.{i}.", h, mask, n_heads, activation, rel_max_sequence)
+        h = decoder_block(sd, f"decoder_layers.{i}.", h, mask, n_heads, activation, rel_max_sequence, rotary)
     return final_norm(h, sd["norm.g"], sd["norm.b"])
 
 
@@ -189,6 +209,30 @@ def relative_forward(sd: StateDict, x: Tensor, n_heads: int, max_sequence: int,
     emb = sd["embedding"]
     h = emb[x.long()]
     h = _trunk(sd, h, causal_mask(S), n_heads, activation, rel_max_sequence=max_sequence)
+    return h @ emb.t()
+
+
+def tied_alibi_forward(sd: StateDict, x: Tensor, n_heads: int, activation: str = "gelu") -> Tensor:
+    """old_models/alibi.py:114-130: ALiBi trunk with the raw `embedding` parameter tied to the output."""
+    emb = sd["embedding"]
+    h = _trunk(sd, emb[x.long()], alibi_mask(x.shape[1], n_heads), n_heads, activation)
+    return h @ emb.t()
+
+
+def rotary_forward(sd: StateDict, x: Tensor, n_heads: int, activation: str = "relu", as_reference: bool = True) -> Tensor:
+    """old_models/rotary_transformer.py:125-144: rotary q/k, plain causal mask, tied embedding.
+
+    as_reference: the reference's forward calls ``self.pos_embed(x)`` with the int64 TOKEN tensor, and
+    FixedPositionalEmbedding.forward ends in ``.to(x)`` (rotary_transformer.py:41-42,133): the sin | cos table is cast
+    to int64, i.e. truncated toward zero, before it multiplies q and k (cos = 1 only where the angle is exactly
+    0, sin = 0 everywhere).  That is what the reference computes, so it is what parity means; as_reference=False
+    gives the intended rotation."""
+    emb = sd["embedding"]
+    S, d = x.shape[1], emb.shape[1]
+    cos, sin = rotary_tables(S, d // n_heads)
+    if as_reference:
+        cos, sin = cos.to(torch.int64).to(torch.float32), sin.to(torch.int64).to(torch.float32)
+    h = _trunk(sd, emb[x.long()], causal_mask(S), n_heads, activation, rotary=(cos, sin))
     return h @ emb.t()
 
 

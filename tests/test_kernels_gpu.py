@@ -427,6 +427,25 @@ def test_adamw_multi_matches_torch():
         assert float((p.cpu() - r.detach()).abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rope_qk_matches_reference_formula_and_inverts(dtype):
+    from oracle import reference_port as O
+    ops = _ops()
+    B, S, H, dh = 2, 37, 3, 16
+    g = torch.Generator().manual_seed(4)
+    qkv = torch.randn(B, S, 3 * H * dh, generator=g).to(dtype)
+    cos, sin = O.rotary_tables(S, dh)
+    q, k, v = (t.reshape(B, S, H, dh).permute(0, 2, 1, 3).float() for t in qkv.split(H * dh, -1))
+    want = torch.cat([O.apply_rotary(t, cos, sin).permute(0, 2, 1, 3).reshape(B, S, H * dh) for t in (q, k)]
+                     + [v.permute(0, 2, 1, 3).reshape(B, S, H * dh)], -1)
+    got = ops.rope_qk_(qkv.clone().cuda(), cos.cuda(), sin.cuda(), H)
+    tol = 1e-6 if dtype == torch.float32 else 4e-2          # bf16: one rounding of values up to ~5
+    assert float((got.float().cpu() - want).abs().max()) < tol
+    assert torch.equal(got[..., 2 * H * dh:].cpu(), qkv[..., 2 * H * dh:])              # v untouched
+    back = ops.rope_qk_(got.clone(), cos.cuda(), sin.cuda(), H, inverse=True)
+    assert float((back.float().cpu() - qkv.float()).abs().max()) < (1e-5 if dtype == torch.float32 else 8e-2)
+
+
 def test_bad_arguments_fail_loudly():
     ops = _ops()
     from musicgeneration_amd._lib import MgxError

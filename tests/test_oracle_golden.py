@@ -143,3 +143,24 @@ def test_greedy_separated():
 def test_synthetic_stream_is_valid_vocab():
     t = O.synthetic_unified_tokens(3, 257, seed=7)
     assert t.shape == (3, 257) and t.min() >= 0 and t.max() < 618 and (t[:, 0] == 0).all()
+
+
+@pytest.mark.parametrize("name,fwd", [("alibi_tied_tiny", "tied"), ("rotary_tiny", "rotary"), ("rotary_dh64_s320", "rotary")])
+def test_old_model_variants(name, fwd):
+    """old_models/alibi.py (tied embedding) and old_models/rotary_transformer.py: logits, loss and every
+    gradient of the oracle against the reference's."""
+    z = gu.load(name)
+    sd = O.make_trainable({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.") and k != "sd.pos_embed.emb"})
+    x = torch.from_numpy(z["x"])
+    heads = 8 if "tiny" in name else 4
+    logits = O.tied_alibi_forward(sd, x, heads) if fwd == "tied" else O.rotary_forward(sd, x, heads)
+    assert gu.rel_err(logits, z["logits"]) < TOL
+    loss = torch.nn.functional.cross_entropy(logits.transpose(-1, -2), torch.roll(x, -1, 1))
+    assert abs(float(loss.detach()) - float(z["loss"])) < TOL * abs(float(z["loss"]))
+    loss.backward()
+    for k in z.files:
+        if k.startswith("grad."):
+            assert gu.rel_err(sd[k[5:]].grad, z[k]) < 2 * TOL, k
+    if fwd == "rotary":                                   # the sin | cos buffer of FixedPositionalEmbedding
+        cos, sin = O.rotary_tables(z["sd.pos_embed.emb"].shape[0], z["sd.pos_embed.emb"].shape[1])
+        assert torch.equal(torch.cat((sin, cos), -1), torch.from_numpy(z["sd.pos_embed.emb"]))
