@@ -194,6 +194,20 @@ long mgx_gemm_tn_workspace_floats(int M, int N, int K, int* splits_out);
 int mgx_gemm_tn_bf16(const void* A, const void* B, void* C, float* workspace, int M, int N, int K,
                      int lda, int ldb, int out_dtype, void* stream);
 
+/* ---- decode-time projections (M <= 256 token rows) --------------------------------------------------
+ * out[M,N] (bf16) = epilogue(A[M,K] . Wt[N,K]^T + bias[N]); A, Wt, res, out bf16 row-major; bias / gamma / beta fp32.
+ * Replaces, for the three token rows per sequence of a sampling step (inference_unified.py:15), Conv1d.forward /
+ * nn.Linear (base_layers.py:54-57, alibi_unified.py:90,92) together with what follows them in the block:
+ *   mode 0: nothing more (c_attn)               mode 1 / 2: GELU (exact erf) / ReLU (linear1, alibi_unified.py:90)
+ *   mode 3: LayerNorm(. + res) * gamma + beta   (c_proj + norm1, linear2 + norm2: alibi_unified.py:88-89,92-94)
+ * Split over N/64 column tiles x K slices (~one workgroup per CU) with fp32 partial slabs in `workspace`
+ * (mgx_skinny_gemm_workspace_floats floats), reduced by a second launch that applies the epilogue.
+ * N % 64 == 0, K % 64 == 0; mode 3 needs N <= 2048. */
+long mgx_skinny_gemm_workspace_floats(int M, int N, int K);
+int mgx_skinny_gemm_bf16(const void* A, const void* Wt, const float* bias, const void* res, const float* gamma,
+                         const float* beta, float eps, void* out, float* workspace, int M, int N, int K, int mode,
+                         void* stream);
+
 /* ---- rotary position embedding on the packed projection ------------------------------------------
  * Replaces rotate_every_two / apply_rotary_pos_emb (old_models/rotary_transformer.py:9-21): q and k of
  * qkv [B,S,3,H,dh] are rotated IN PLACE pair-wise by the angles of cos_tab / sin_tab [S, dh/2] fp32
@@ -218,6 +232,10 @@ int mgx_rope_qk(void* qkv, const float* cos_tab, const float* sin_tab, int B, in
  * Integer work, bit-exact. */
 int mgx_unified_decode_events(const int* tokens, int B, int L, const int* dur_ticks, int note_bins, int velocity_bins,
                               int duration_bins, int* events, int* abs_time, int* counts, void* stream);
+/* Separated stream (SeparatedReconstruct.reconstruct_stream, data/transforms.py:290-318): tokens [B,3,L] int32
+ * (note / velocity / duration rows); outputs as mgx_unified_decode_events (counts is never negative here). */
+int mgx_separated_decode_events(const int* tokens, int B, int L, const int* dur_ticks, int note_bins, int velocity_bins,
+                                int duration_bins, int* events, int* abs_time, int* counts, void* stream);
 int mgx_unified_encode_tokens(const int* notes, const int* velocities, const int* durations, const int* lengths,
                               const int* starts, int B, int Nmax, int seq_len, int note_bins, int velocity_bins,
                               int duration_bins, int* tokens, void* stream);

@@ -39,8 +39,11 @@ PROTOTYPES = {
     "mgx_kv_append_at": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "mgx_decode_step_attn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "mgx_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _i, _vp]),
+    "mgx_skinny_gemm_workspace_floats": (C.c_long, [_i, _i, _i]),
+    "mgx_skinny_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mgx_rope_qk": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mgx_unified_decode_events": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mgx_separated_decode_events": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mgx_unified_encode_tokens": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mgx_adamw_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "mgx_gemm_nt_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _vp]),

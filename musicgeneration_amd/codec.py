@@ -103,6 +103,32 @@ class UnifiedReconstruct:
         return out
 
 
+@dataclass
+class SeparatedReconstruct(UnifiedReconstruct):
+    """data/transforms.py:277-323: the three-row (note, velocity, duration) stream of the separated model."""
+
+    def decode_batch(self, tokens: torch.Tensor):
+        """tokens [B,3,L] -> (events [B,L,3], abs_time [B,L], counts [B]) int32."""
+        if tokens.dim() != 3 or tokens.shape[1] != 3:
+            raise ValueError("tokens must be [B, 3, L]")
+        tk = tokens.to(torch.int32).contiguous()
+        _need(tk, "tokens", torch.int32)
+        B, _, L = tk.shape
+        events = torch.empty(B, L, 3, dtype=torch.int32, device=tk.device)
+        abs_time = torch.empty(B, L, dtype=torch.int32, device=tk.device)
+        counts = torch.empty(B, dtype=torch.int32, device=tk.device)
+        check(lib.mgx_separated_decode_events(_p(tk), B, L, _p(self._table(tk.device)), self.note_bins,
+                                              self.velocity_bins, self.duration_lin_bins, _p(events), _p(abs_time),
+                                              _p(counts), _stream()), "mgx_separated_decode_events")
+        return events, abs_time, counts
+
+    def reconstruct_stream(self, arr) -> MidiStream:
+        t = torch.as_tensor(np.asarray(arr) if not isinstance(arr, torch.Tensor) else arr)
+        if not t.is_cuda:
+            t = t.cuda()
+        return self.reconstruct_streams(t.reshape(1, 3, -1))[0]
+
+
 def encode_unified(notes: torch.Tensor, velocities: torch.Tensor, durations: torch.Tensor, lengths: torch.Tensor,
                    starts: torch.Tensor, seq_len: int, note_bins=89, velocity_bins=127, duration_bins=200):
     """[B,Nmax] binned events (+ lengths, window starts [B]) -> token rows [B,seq_len] int32."""

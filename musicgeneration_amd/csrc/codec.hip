@@ -203,7 +203,83 @@ __global__ __launch_bounds__(CT) void unified_encode_kernel(const int* __restric
     }
 }
 
+// Separated stream: tokens [B,3,L] (note / velocity / duration rows) -> events, abs_time, counts as above
+// (SeparatedReconstruct.reconstruct_stream, data/transforms.py:290-318).
+__global__ __launch_bounds__(CT) void separated_decode_kernel(const int* __restrict__ tokens, int L,
+                                                               const int* __restrict__ dur_ticks, int note_bins,
+                                                               int velocity_bins, int duration_bins,
+                                                               int* __restrict__ events, int* __restrict__ abs_time,
+                                                               int* __restrict__ counts) {
+    __shared__ int lds[17];
+    __shared__ int s_any0, s_any1, s_first1n;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int* tn = tokens + (long)b * 3 * L;
+    const int* tv = tn + L;
+    const int* td = tn + 2 * L;
+    int* ev = events + (long)b * L * 3;
+    int* at = abs_time + (long)b * L;
+    if (tid == 0) {
+        s_any0 = 0;
+        s_any1 = 0;
+        s_first1n = L;
+    }
+    __syncthreads();
+    int a0 = 0;
+    for (int i = tid; i < L; i += CT) a0 |= (tn[i] == 0) | (tv[i] == 0) | (td[i] == 0);
+    if (a0) s_any0 = 1;                                           // benign race: every writer stores 1
+    __syncthreads();
+    const int beg = s_any0 ? 1 : 0;                               // transforms.py:297-298
+    int a1 = 0, m1 = L;
+    for (int i = beg + tid; i < L; i += CT) {
+        a1 |= (tn[i] == 1) | (tv[i] == 1) | (td[i] == 1);
+        if (tn[i] == 1) m1 = min(m1, i);
+    }
+    if (a1) s_any1 = 1;
+    if (m1 < L) atomicMin(&s_first1n, m1);
+    __syncthreads();
+    // any 1 in ANY row cuts at the first 1 of the NOTE row; argmax of an all-false row is 0: nothing survives
+    const int end = s_any1 ? (s_first1n < L ? s_first1n : beg) : L;
+    int kept = 0, tbase = 0;
+    for (int c0 = beg; c0 < end; c0 += CT) {
+        const int i = c0 + tid;
+        int n = 0, v = 0, d = 0, keep = 0, dt = 0;
+        if (i < end) {
+            n = clampi(tn[i] - 2, 0, note_bins) - 1;
+            v = clampi(tv[i] - 2, 0, velocity_bins);
+            d = dur_ticks[clampi(td[i] - 2, 0, duration_bins - 1)];
+            keep = (v != 0) | (n == -1);
+            dt = (keep && n == -1) ? d : 0;
+        }
+        int tk_, tt;
+        const int ok = block_scan(keep, &tk_, lds);
+        const int ot = block_scan(dt, &tt, lds);
+        if (keep) {
+            const long o = kept + ok;
+            ev[3 * o + 0] = n;
+            ev[3 * o + 1] = v;
+            ev[3 * o + 2] = d;
+            at[o] = tbase + ot;
+        }
+        kept += tk_;
+        tbase += tt;
+    }
+    if (tid == 0) counts[b] = kept;
+}
+
 }  // namespace
+
+extern "C" int mgx_separated_decode_events(const int* tokens, int B, int L, const int* dur_ticks, int note_bins,
+                                           int velocity_bins, int duration_bins, int* events, int* abs_time,
+                                           int* counts, void* stream) {
+    MGX_REQUIRE(tokens && dur_ticks && events && abs_time && counts, MGX_EINVAL, "mgx_separated_decode_events: null pointer");
+    MGX_REQUIRE(B > 0 && L > 0, MGX_EINVAL, "mgx_separated_decode_events: B=%d L=%d", B, L);
+    MGX_REQUIRE(note_bins > 0 && velocity_bins > 0 && duration_bins > 0, MGX_EINVAL,
+                "mgx_separated_decode_events: bins %d/%d/%d", note_bins, velocity_bins, duration_bins);
+    hipLaunchKernelGGL(separated_decode_kernel, dim3(B), dim3(CT), 0, (hipStream_t)stream, tokens, L, dur_ticks,
+                       note_bins, velocity_bins, duration_bins, events, abs_time, counts);
+    MGX_CHECK_LAUNCH("separated_decode");
+    return MGX_OK;
+}
 
 extern "C" int mgx_unified_decode_events(const int* tokens, int B, int L, const int* dur_ticks, int note_bins,
                                          int velocity_bins, int duration_bins, int* events, int* abs_time, int* counts,

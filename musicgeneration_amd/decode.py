@@ -38,6 +38,7 @@ class KVCacheDecoder:
         self.caches = [(torch.zeros(batch, H, max_len, dh, dtype=self.dtype, device=self.device),
                         torch.zeros(batch, H, max_len, dh, dtype=self.dtype, device=self.device))
                        for _ in model.decoder_layers]
+        self._ws = None                                   # fp32 split-K workspace of the decode projections
         with torch.no_grad():
             self._head_wb = tuple(t.detach() for t in model.head_weights(self.dtype))   # cast once per decoder
 
@@ -65,10 +66,31 @@ class KVCacheDecoder:
             if R > 4 and pos0 != 0:
                 raise ValueError("prefill (more than 4 rows) must start at position 0")
         T = B * R
+        ff = m.decoder_layers[0].linear1.weight.shape[0]
+        skinny = (os.environ.get("MGX_DECODE_GEMM", "mgx") == "mgx" and dt == torch.bfloat16 and T <= 256 and R <= 4
+                  and d % 64 == 0 and ff % 64 == 0 and d <= 2048
+                  and ops.decode_step_attn_supported(dt, d // m.decoder_layers[0].heads))
+        if skinny:
+            need = max(ops.skinny_workspace_floats(T, n, k) for n, k in ((3 * d, d), (d, d), (ff, d), (d, ff)))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.float32, device=self.device)
         for layer, (kc, vc) in zip(m.decoder_layers, self.caches):
             W = layer.weights(dt)
-            wqkv, bqkv, wp, bp, w1, w2, b2 = W.wqkv, W.bqkv, W.wp, W.bp, W.w1, W.w2, W.b2
             x2 = h.reshape(T, d)
+            if skinny:
+                # decode projections on libmgx: K-split weight streaming + the block's elementwise tail in the
+                # reduction (bias | bias+activation | bias+residual+LayerNorm): 8 short launches per layer
+                # instead of 4 latency-bound library GEMMs + 2 LayerNorm + 1 bias-activation kernels
+                ws = self._ws
+                qkv = ops.skinny_gemm(x2, W.wqkv_t, W.m_bqkv, ws).view(B, R, 3 * d)
+                a = ops.decode_step_attn(qkv, kc, vc, layer.attn.slopes, pos0)
+                h1 = ops.skinny_gemm(a.view(T, d), W.wp_t, W.m_bp, ws, res=x2, gamma=W.m_g1, beta=W.m_be1,
+                                     eps=layer.norm1.eps)
+                hact = ops.skinny_gemm(h1, W.w1, W.m_b1, ws, act=layer.activation)
+                h2 = ops.skinny_gemm(hact, W.w2, W.m_b2, ws, res=h1, gamma=W.m_g2, beta=W.m_be2, eps=layer.norm2.eps)
+                h = h2.view(B, R, d)
+                continue
+            wqkv, bqkv, wp, bp, w1, w2, b2 = W.wqkv, W.bqkv, W.wp, W.bp, W.w1, W.w2, W.b2
             qkv = torch.addmm(bqkv, x2, wqkv).view(B, R, 3 * d)
             if R <= 4 and ops.decode_step_attn_supported(dt, d // layer.heads):
                 a = ops.decode_step_attn(qkv, kc, vc, layer.attn.slopes, pos0)      # append + attend, one launch

@@ -561,6 +561,46 @@ def decode_step_attn(qkv, kcache, vcache, slopes, pos0):
     return out
 
 
+_SKINNY_MODE = {None: 0, "gelu": 1, "relu": 2, "ln": 3}
+
+
+def skinny_gemm_supported(x: torch.Tensor, wt: torch.Tensor) -> bool:
+    """Shapes mgx_skinny_gemm_bf16 takes: bf16, at most 256 rows, N % 64 == 0, K % 64 == 0."""
+    return (x.dtype == torch.bfloat16 and wt.dtype == torch.bfloat16 and x.dim() == 2 and wt.dim() == 2
+            and 0 < x.shape[0] <= 256 and wt.shape[0] % 64 == 0 and x.shape[1] % 64 == 0
+            and x.is_contiguous() and wt.is_contiguous())
+
+
+def skinny_workspace_floats(M: int, N: int, K: int) -> int:
+    return int(lib.mgx_skinny_gemm_workspace_floats(M, N, K))
+
+
+def skinny_gemm(x, wt, bias, workspace, act=None, res=None, gamma=None, beta=None, eps=1e-5):
+    """Decode projection: epilogue(x[M,K] @ wt[N,K]^T + bias).  act: None | 'gelu' | 'relu'; with `res`:
+    LayerNorm(. + res) * gamma + beta.  `workspace`: fp32 tensor of >= skinny_workspace_floats(M, N, K) elements."""
+    _need(x, "x", torch.bfloat16)
+    _need(wt, "wt", torch.bfloat16)
+    _need(bias, "bias", torch.float32)
+    _need(workspace, "workspace", torch.float32)
+    M, K = x.shape
+    N, K2 = wt.shape
+    if K != K2 or bias.numel() != N:
+        raise ValueError(f"skinny_gemm: x {tuple(x.shape)} wt {tuple(wt.shape)} bias {bias.numel()}")
+    mode = _SKINNY_MODE["ln" if res is not None else act]
+    if res is not None:
+        _need(res, "res", torch.bfloat16)
+        _need(gamma, "gamma", torch.float32)
+        _need(beta, "beta", torch.float32)
+        if res.shape != (M, N) or gamma.numel() != N or beta.numel() != N or act is not None:
+            raise ValueError("skinny_gemm: residual/LayerNorm operands do not match (and exclude an activation)")
+    if workspace.numel() < skinny_workspace_floats(M, N, K):
+        raise ValueError("skinny_gemm: workspace too small")
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    check(lib.mgx_skinny_gemm_bf16(_p(x), _p(wt), _p(bias), _p(res), _p(gamma), _p(beta), float(eps), _p(out),
+                                   _p(workspace), M, N, K, mode, _stream()), "mgx_skinny_gemm_bf16")
+    return out
+
+
 # ---------------------------------------------------------------------------
 # optimizer
 # ---------------------------------------------------------------------------

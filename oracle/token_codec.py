@@ -7,6 +7,7 @@ Follows (reference file:line):
   window + pad             data/transforms.py:172-179
   UnifiedReconstruct.reconstruct_stream   data/transforms.py:339-365
   unflatten_notes_         data/transforms.py:94-128
+  SeparatedReconstruct.reconstruct_stream data/transforms.py:290-318
   stream_to_raw_stream_    data/parse_midi_numba.py:189-211
   compute_lin_bin          data/parse_midi_numba.py:251-252
 
@@ -99,3 +100,22 @@ def stream_to_raw_events(events):
             out.append([1, t + d, n + 21, 0])
     out = np.asarray(out, dtype=events.dtype).reshape(-1, 4)
     return out[np.argsort(out[:, 1], kind="mergesort")]
+
+
+def reconstruct_events_separated(tokens, note_bins=NOTE_BINS, velocity_bins=VELOCITY_BINS, duration_bins=DURATION_BINS,
+                                 ticks=TICKS):
+    """tokens [3,L] (note, velocity, duration rows) -> MidiStream.events [N,3] (transforms.py:290-318)."""
+    arr = np.array(tokens, dtype=np.int64)
+    if (arr == 0).any():
+        arr = arr[:, 1:]
+    if (arr == 1).any():
+        arr = arr[:, :np.argmax(arr[0] == 1)]        # first 1 of the NOTE row; 0 (empty result) when it has none
+    arr = arr - 2
+    arr[0] = np.clip(arr[0], 0, note_bins)
+    arr[1] = np.clip(arr[1], 0, velocity_bins)
+    arr[2] = np.clip(arr[2], 0, duration_bins - 1)
+    arr[0] -= 1
+    keep, = np.where((arr[1] != 0) | (arr[0] == -1))
+    arr = arr[:, keep]
+    arr[2] = duration_ticks_table(duration_bins, ticks)[arr[2]]
+    return arr.transpose(1, 0)

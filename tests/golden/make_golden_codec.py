@@ -73,3 +73,28 @@ out["n_enc"] = np.array(len(cases)); out["n_dec"] = np.array(len(dec_rows))
 out["bin_arr"] = rc.bin_arr
 np.savez_compressed(os.path.join(HERE, "codec_unified.npz"), **out)
 print("wrote codec_unified.npz", len(cases), "encode cases,", len(dec_rows), "decode cases")
+
+# ---- separated stream (SeparatedReconstruct, transforms.py:277-323) ----------------------------------------
+sep = {}
+src = T.SeparatedReconstruct()
+rows3 = []
+for k, L in enumerate([48, 300, 1023, 64, 64, 64]):
+    a = np.stack([rng.integers(2, 92, L), rng.integers(2, 130, L), rng.integers(2, 203, L)]).astype(np.int64)
+    a[1, rng.random(L) < 0.15] = 2                 # velocity 0 after the -2 shift: dropped unless a time shift
+    a[0, rng.random(L) < 0.3] = 2                  # note 0 -> -1 after the shifts: a time shift
+    if k != 3:
+        a[:, 0] = 0                                # BOS column
+    if k in (0, 1, 2):
+        a[:, L - L // 5:] = 1                      # EOS / padding tail
+    if k == 4:
+        a[2, 10] = 1                               # a 1 outside the note row: argmax(arr[0] == 1) == 0 -> empty result
+    if k == 5:
+        a[0, 20] = 1
+    rows3.append(a)
+for k, a in enumerate(rows3):
+    st = src.reconstruct_stream(a)
+    raw = P.stream_to_raw_stream_(st.events) if st.events.shape[0] else np.zeros((0, 4), np.int64)
+    sep[f"dec{k}.tokens"], sep[f"dec{k}.events"], sep[f"dec{k}.raw"] = a, st.events, raw
+sep["n_dec"] = np.array(len(rows3))
+np.savez_compressed(os.path.join(HERE, "codec_separated.npz"), **sep)
+print("wrote codec_separated.npz", len(rows3), "decode cases")

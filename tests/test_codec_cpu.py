@@ -37,3 +37,12 @@ def test_round_trip_of_a_clean_stream():
     ev = C.reconstruct_events(row)
     assert np.array_equal(ev[:, 0], notes - 1) and np.array_equal(ev[:, 1], vel)
     assert np.array_equal(ev[:, 2], C.duration_ticks_table()[dur])
+
+
+def test_separated_decode_matches_reference():
+    zs = np.load(os.path.join(os.path.dirname(__file__), "golden", "codec_separated.npz"))
+    for k in range(int(zs["n_dec"])):
+        ev = C.reconstruct_events_separated(zs[f"dec{k}.tokens"])
+        assert np.array_equal(ev, zs[f"dec{k}.events"].reshape(-1, 3)), k
+        raw = C.stream_to_raw_events(ev) if ev.shape[0] else np.zeros((0, 4), np.int64)
+        assert np.array_equal(raw, zs[f"dec{k}.raw"]), k

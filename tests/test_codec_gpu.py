@@ -88,3 +88,24 @@ def test_encode_ragged_batch_vs_oracle_and_round_trip():
     n = lens[b] - first
     assert np.array_equal(ev[:, 0], notes[b, first:lens[b]] - 1) and ev.shape[0] == n
     assert np.array_equal(ev[:, 2], C.duration_ticks_table()[dur[b, first:lens[b]]])
+
+
+def test_separated_decode_golden_and_random():
+    from musicgeneration_amd.codec import SeparatedReconstruct
+    zs = np.load(os.path.join(os.path.dirname(__file__), "golden", "codec_separated.npz"))
+    rc = SeparatedReconstruct()
+    for k in range(int(zs["n_dec"])):
+        tok = torch.from_numpy(zs[f"dec{k}.tokens"]).cuda()
+        s = rc.reconstruct_stream(tok)
+        assert np.array_equal(s.events.reshape(-1, 3), zs[f"dec{k}.events"].reshape(-1, 3)), k
+        raw = rc.raw_streams(tok.reshape(1, 3, -1))[0]
+        assert np.array_equal(raw.events, zs[f"dec{k}.raw"].reshape(-1, 4)), k
+    rng = np.random.default_rng(9)
+    for L in (1, 7, 1024, 1025, 4161):
+        tok = np.stack([rng.integers(2, 92, (5, L)), rng.integers(2, 130, (5, L)), rng.integers(2, 203, (5, L))], 1)
+        tok[1, :, 0] = 0
+        tok[2, 0, L // 2:] = 1
+        tok[3, 2, L // 3] = 1
+        streams = rc.reconstruct_streams(torch.from_numpy(tok).cuda())
+        for b in range(5):
+            assert np.array_equal(streams[b].events.reshape(-1, 3), C.reconstruct_events_separated(tok[b])), (L, b)

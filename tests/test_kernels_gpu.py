@@ -446,6 +446,35 @@ def test_rope_qk_matches_reference_formula_and_inverts(dtype):
     assert float((back.float().cpu() - qkv.float()).abs().max()) < (1e-5 if dtype == torch.float32 else 8e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(192, 3072, 1024), (192, 1024, 4096), (3, 1024, 1024), (256, 4096, 1024),
+                                   (50, 128, 192), (17, 64, 64)])
+@pytest.mark.parametrize("mode", ["bias", "gelu", "relu", "ln"])
+def test_skinny_gemm(M, N, K, mode):
+    """Decode projections (mgx_skinny_gemm_bf16) against fp32 torch on the same bf16 operands."""
+    ops = _ops()
+    if mode == "ln" and N > 2048:
+        pytest.skip("LayerNorm epilogue covers N <= 2048")
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    wt = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    bias = 0.1 * torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).bfloat16()
+    gamma, beta = 1 + 0.1 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    ws = torch.empty(ops.skinny_workspace_floats(M, N, K), dtype=torch.float32).cuda()
+    pre = (x.float() @ wt.float().t() + bias).bfloat16().float()
+    if mode == "ln":
+        out = ops.skinny_gemm(x.cuda(), wt.cuda(), bias.cuda(), ws, res=res.cuda(), gamma=gamma.cuda(), beta=beta.cuda())
+        ref = torch.nn.functional.layer_norm(pre + res.float(), (N,), gamma, beta, 1e-5)
+    else:
+        act = None if mode == "bias" else mode
+        out = ops.skinny_gemm(x.cuda(), wt.cuda(), bias.cuda(), ws, act=act)
+        ref = pre if act is None else getattr(torch.nn.functional, act)(pre)
+    assert out.shape == (M, N) and out.dtype == torch.bfloat16
+    # one bf16 rounding of the result + accumulation-order noise on the pre-activation's own rounding
+    assert float((out.float().cpu() - ref).abs().max()) < 0.03 * float(ref.abs().max().clamp_min(1.0))
+    assert gu.rel_err(out.float(), ref) < BF16_TOL
+
+
 def test_bad_arguments_fail_loudly():
     ops = _ops()
     from musicgeneration_amd._lib import MgxError
