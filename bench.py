@@ -227,8 +227,12 @@ def main():
         fl = sum(w for _, _, w in ev)
         ach = fl / (tot_ms * 1e-3) / 1e12
         traffic = None
-        if name == "alibi_attn_fwd" and a.workload == "train_unified" and (B, S, H, dh) == (16, 2048, 8, 128):
-            traffic = pmc_traffic("attn_fwd_mfma_kernel<128,8> B16 S2048 H8")
+        if a.workload == "train_unified" and a.dtype == "bf16" and (B, S, H, dh) == (16, 2048, 8, 128):   # d=1024 ff=4096 fixed by the workload
+            traffic = pmc_traffic({
+                "alibi_attn_fwd": "attn_fwd_mfma_kernel<128,8> B16 S2048 H8",
+                "alibi_attn_bwd": "attn_bwd dkv+dq+delta <128> B16 S2048 H8 (per backward = per dkv launch)",
+                "gemm_tn": "gemm_tn_kernel + splitk_reduce, mean of dw2/dw1/dwp/dwqkv at T=32768 d=1024 ff=4096",
+                "gemm_nt": "gemm_nt_kernel<gelu,dropout> mlp1 T=32768 d=1024 ff=4096"}.get(name, ""))
         lines.append({"bound": "mfma", "kernel": labels[name], "achieved": ach, "peak": PEAK_BF16_TFLOPS,
                       "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                       "traffic_unit": "HBM bytes per launch (TCC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic_pmc.json)",

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): bash tools/traffic.sh   -- HBM traffic of the two roofline kernels from the TCC counters.
+# usage (GPU box): bash tools/traffic.sh   -- HBM traffic of the roofline kernels from the TCC counters.
 # FETCH_SIZE and WRITE_SIZE do not fit one pass (3 + 2 of the 4 TCC slots): one rocprofv3 run per counter.
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
@@ -9,6 +9,10 @@ run() {  # tag counter script args...
 }
 run attn_fetch FETCH_SIZE $R/tools/attn_bench.py 16 2048 8 128 3 fwd && \
 run attn_write WRITE_SIZE $R/tools/attn_bench.py 16 2048 8 128 3 fwd && \
+run attnb_fetch FETCH_SIZE $R/tools/attn_bench.py 16 2048 8 128 2 bwd && \
+run attnb_write WRITE_SIZE $R/tools/attn_bench.py 16 2048 8 128 2 bwd && \
 run dec_fetch FETCH_SIZE $R/tools/decode_one.py 2112 5 && \
 run dec_write WRITE_SIZE $R/tools/decode_one.py 2112 5 && \
+run tn_fetch FETCH_SIZE $R/tools/gemm_tn_step.py 2 && \
+run tn_write WRITE_SIZE $R/tools/gemm_tn_step.py 2 && \
 python3 $R/tools/traffic_sum.py $R/gpurun_out
