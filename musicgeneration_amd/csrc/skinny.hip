@@ -1,22 +1,28 @@
 // Decode projections: C[M,N] = A[M,K] . Wt[N,K]^T with M <= 256 token rows (batch x 3 rows per sampling step,
 // musicgeneration_amd/decode.py) -- the x@W of Conv1d.forward / nn.Linear (base_layers.py:54-57,
-// alibi_unified.py:90,92) at decode time, with the rest of the block's elementwise tail folded into the
-// reduction: bias, GELU/ReLU (alibi_unified.py:90), or residual + LayerNorm (alibi_unified.py:88-89,92-94).
+// alibi_unified.py:90,92) at decode time, with the rest of the block's elementwise tail folded in:
+// bias, GELU/ReLU (alibi_unified.py:90), or residual + LayerNorm (alibi_unified.py:88-89,92-94).
 //
-// A library GEMM at M = 192 is a latency chain (one workgroup walks all of K: ~12 us for 1-8 MB of weights).
-// Here the work is cut N/64 x SPLITS ways so that ~128-256 workgroups each stream a short K slice:
-//   skinny_partial_kernel   grid (N/64, SPLITS), 4 waves; every wave owns up to four 16-row blocks x 64 columns
-//                           (v_mfma_f32_16x16x32_bf16), operands straight global -> registers (each weight byte
-//                           is used once per workgroup: an LDS round trip would only add latency), one k step
-//                           prefetched ahead; fp32 partial tile -> slab [SPLITS][M][N]
+// A library GEMM at M = 192 is a latency chain (~9-15 us for 2-8 MB of weights) followed by separate elementwise
+// launches.  Here the work is cut (N/64) x (M/64) x SPLITS ways into >= ~128 workgroups:
+//   skinny_partial_kernel   grid (N/64, SPLITS, M/64), 4 waves; 64 rows x 64 columns x one K slice (up to 1024
+//                           deep) per workgroup on v_mfma_f32_16x16x32_bf16.  SPLITS == 1 (the wide projections
+//                           qkv and linear1): bias / activation applied in place, bf16 result, no second launch.
+//                           SPLITS > 1 (the d x d and ff x d projections): fp32 partial tile -> slab [SPLITS][M][N]
 //   skinny_reduce[_ln]_kernel  sum of the slabs + bias, then the epilogue of the site (elementwise: one thread per
 //                           8 columns; LayerNorm: one wave per token row)
-// Both are plain stream-ordered launches (the slabs cross a kernel boundary, no in-launch hand-off).
+// Slabs are what a split costs (written, then read back dirty: ~6 us per 12 MB measured), so the slice is as deep
+// as LDS allows before K is split.  Plain stream-ordered launches (no in-launch hand-off).
 #include "mgx_common.h"
 
 namespace {
 
-constexpr int SK_BN = 64, SK_KC = 256;       // column tile; deepest K slice (A slice in LDS: 256 rows x 256 k x 2 B = 128 KiB)
+constexpr int SK_BN = 64;      // column tile
+constexpr int SK_BM = 64;      // row tile (A slice in LDS: 64 rows x 1024 k x 2 B = 128 KiB at the deepest slice)
+constexpr int SK_TS = 68;      // floats per row of the output tile in LDS
+#ifndef SK_MIN_WG
+#define SK_MIN_WG 128
+#endif
 
 // A-slice image: [k block of 64][row][64 k] = 128-byte rows, 16-byte chunk index XORed with (row >> 1) & 7
 // (gemm.hip's NT image: full 128-byte lines per LDS-DMA piece, conflict-free ds_read_b128 for the 16x16x32 operand)
@@ -24,15 +30,28 @@ __device__ __forceinline__ int sk_img(int row, int ch) {
     return 1024 * (row >> 3) + 128 * (row & 7) + 16 * (ch ^ ((row >> 1) & 7));
 }
 
-// grid (N/64, SPLITS), 4 waves.  The workgroup's activation slice A[:, kbeg:kend] (all M rows, shared by the four
-// waves) is staged once by LDS-DMA; each wave owns 16 output columns and issues every load of its weight rows for
-// the whole slice up front (KS x 16 B per lane), so the workgroup pays ONE memory round trip; then KS k steps of
-// {NRB row-block fragments from LDS, v_mfma_f32_16x16x32_bf16}.  NRB = 16-row blocks (M rounded up; rows past M
-// are clamped copies whose results are dropped), KS = k steps of 32 in the slice: compile-time, so the
-// accumulators stay in registers.
+__device__ __forceinline__ float sk_gelu(float x) {          // exact-erf GELU via Abramowitz-Stegun 7.1.26 (see elementwise.hip)
+    const float z = x * 0.70710678118654752440f;
+    const float az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);
+    return 0.5f * x * (1.f + copysignf(fmaf(-poly * t, e, 1.f), z));
+}
+
+// grid (N/64, SPLITS, row tiles), 4 waves.  The workgroup's activation slice A[m0 : m0 + 16 NRB, kbeg : kbeg + 32 KS]
+// (shared by the four waves) is staged once by LDS-DMA; each wave owns 16 output columns and issues every load of
+// its weight rows for the whole slice up front (KS x 16 B per lane), so the workgroup pays ONE memory round trip;
+// then KS k steps of {NRB row-block fragments from LDS, MFMA}.  Rows past M are clamped copies whose results are
+// dropped.  NRB and KS are compile-time so the accumulators and the weight fragments stay in registers.
+// mode < 0: fp32 tile -> slab[split]; mode 0 / 1 / 2 (single split): bias / +GELU / +ReLU -> bf16 out.
 template <int NRB, int KS>
 __global__ __launch_bounds__(256) void skinny_partial_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
-                                                              float* __restrict__ slab, int M, int N, int K) {
+                                                              float* __restrict__ slab, const float* __restrict__ bias,
+                                                              bf16_t* __restrict__ outp, int M, int N, int K, int mode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void lds_void;
     constexpr int MPAD = NRB * 16, KC = KS * 32, NKB = KC / 64, GROUPS = MPAD / 8;
@@ -40,6 +59,7 @@ __global__ __launch_bounds__(256) void skinny_partial_kernel(const bf16_t* __res
     const int l15 = lane & 15, g4 = lane >> 4;
     const int n0 = blockIdx.x * SK_BN + 16 * w;          // this wave's 16 columns
     const int split = blockIdx.y;
+    const int m0 = blockIdx.z * MPAD;
     const int kbeg = split * KC;
     // weights: row n0 + l15, k = kbeg + 32*ks + 8*g4: everything in flight at once
     bf16x8 bf[KS];
@@ -51,7 +71,7 @@ __global__ __launch_bounds__(256) void skinny_partial_kernel(const bf16_t* __res
         const int kb = p / GROUPS, gr = p - kb * GROUPS;
         const int row = 8 * gr + (lane >> 3);
         const int ch = (lane & 7) ^ ((row >> 1) & 7);
-        const bf16_t* src = A + (long)min(row, M - 1) * K + kbeg + 64 * kb + 8 * ch;
+        const bf16_t* src = A + (long)min(m0 + row, M - 1) * K + kbeg + 64 * kb + 8 * ch;
         __builtin_amdgcn_global_load_lds((const void*)src, (lds_void*)(smem + (kb * MPAD + 8 * gr) * 128), 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -68,25 +88,37 @@ __global__ __launch_bounds__(256) void skinny_partial_kernel(const bf16_t* __res
             acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks], af, acc[i], 0, 0, 0);
         }
     }
-    // D[row = n][col = m]: the lane holds C row m = 16*i + l15, columns n0 + 4*g4 .. +3
-    float* out = slab + (long)split * M * N;
+    // D[row = n][col = m]: the lane holds C row m0 + 16*i + l15, columns n0 + 4*g4 .. +3.  The tile goes through LDS
+    // (rows of 64 + 4 floats: conflict-free both ways) and leaves as whole row segments.
+    float* tile = reinterpret_cast<float*>(smem);
+    __syncthreads();                                       // every wave is done with the A image
 #pragma unroll
-    for (int i = 0; i < NRB; ++i) {
-        const int m = 16 * i + l15;
-        if (m < M) *reinterpret_cast<f32x4*>(out + (long)m * N + n0 + 4 * g4) = acc[i];
+    for (int i = 0; i < NRB; ++i)
+        *reinterpret_cast<f32x4*>(tile + (16 * i + l15) * SK_TS + 16 * w + 4 * g4) = acc[i];
+    __syncthreads();
+    const int c4 = 4 * (threadIdx.x & 15);
+    const int col = blockIdx.x * SK_BN + c4;
+    const int rows = min(MPAD, M - m0);
+    if (mode < 0) {
+        float* out = slab + (long)split * M * N + (long)m0 * N + col;
+        for (int r = threadIdx.x >> 4; r < rows; r += 16)
+            *reinterpret_cast<f32x4*>(out + (long)r * N) = *reinterpret_cast<const f32x4*>(tile + r * SK_TS + c4);
+        return;
     }
-}
-
-__device__ __forceinline__ float sk_gelu(float x) {          // exact-erf GELU via Abramowitz-Stegun 7.1.26 (see elementwise.hip)
-    const float z = x * 0.70710678118654752440f;
-    const float az = fabsf(z);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);
-    return 0.5f * x * (1.f + copysignf(fmaf(-poly * t, e, 1.f), z));
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + col);
+    bf16_t* out = outp + (long)m0 * N + col;
+    for (int r = threadIdx.x >> 4; r < rows; r += 16) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * SK_TS + c4) + bv;
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e];
+            if (mode == 1) x = sk_gelu((float)(bf16_t)x);    // the activation sees the bf16 pre-activation, as the
+            if (mode == 2) x = fmaxf((float)(bf16_t)x, 0.f); // unfused path (bias_act_fwd on a bf16 GEMM result) does
+            o[e] = (bf16_t)x;
+        }
+        *reinterpret_cast<bf16x4*>(out + (long)r * N) = o;
+    }
 }
 
 // sum over the split slabs of 8 consecutive columns, four slabs per round so that 8 loads are in flight per lane
@@ -193,12 +225,21 @@ __global__ __launch_bounds__(64) void skinny_reduce_ln_kernel(const float* __res
     }
 }
 
-int skinny_splits(int N, int K) {
-    // slice depth 256, 128 or 64 (the instantiated kernels): the deepest that divides K, then shallower while the
-    // grid is under ~one workgroup per two CUs (the slabs grow with the slice count)
-    const int tiles = N / SK_BN;
-    int kc = K % 256 == 0 ? 256 : (K % 128 == 0 ? 128 : 64);
-    while (kc > 64 && tiles * (K / kc) < 128) kc /= 2;
+// rows per workgroup tile (16-row blocks) and the number of row tiles
+void skinny_rows(int M, int* nrb, int* mtiles) {
+    *nrb = M >= SK_BM ? SK_BM / 16 : (M + 15) / 16;
+    *mtiles = (M + 16 * *nrb - 1) / (16 * *nrb);
+}
+
+int skinny_splits(int M, int N, int K) {
+    // the deepest slice (1024 ... 64, the instantiated depths) that divides K and still gives >= 128 workgroups
+    int nrb, mtiles;
+    skinny_rows(M, &nrb, &mtiles);
+    const int tiles = (N / SK_BN) * mtiles;
+    int kc = 64;
+    for (int c = 1024; c >= 64; c /= 2)
+        if (K % c == 0) { kc = c; break; }
+    while (kc > 64 && tiles * (K / kc) < SK_MIN_WG) kc /= 2;
     return K / kc;
 }
 
@@ -206,7 +247,7 @@ int skinny_splits(int N, int K) {
 
 extern "C" long mgx_skinny_gemm_workspace_floats(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || N % SK_BN || K % 64) return 0;
-    return (long)skinny_splits(N, K) * M * N;
+    return (long)skinny_splits(M, N, K) * M * N;
 }
 
 extern "C" int mgx_skinny_gemm_bf16(const void* A, const void* Wt, const float* bias, const void* res,
@@ -219,31 +260,35 @@ extern "C" int mgx_skinny_gemm_bf16(const void* A, const void* Wt, const float* 
     MGX_REQUIRE(mode >= 0 && mode <= 3, MGX_EINVAL, "mgx_skinny_gemm_bf16: bad mode %d", mode);
     MGX_REQUIRE(mode != 3 || (res && gamma && beta && N <= 64 * 8 * 4), MGX_EINVAL,
                 "mgx_skinny_gemm_bf16: LayerNorm mode needs res/gamma/beta and N <= 2048 (N=%d)", N);
-    const int splits = skinny_splits(N, K);
+    const int splits = skinny_splits(M, N, K);
     const int kc = K / splits;
     hipStream_t st = (hipStream_t)stream;
-    const int nrb = (M + 15) / 16;
-    const int NRB = nrb <= 1 ? 1 : (nrb <= 4 ? 4 : (nrb <= 8 ? 8 : (nrb <= 12 ? 12 : 16)));
-    const size_t lds = (size_t)NRB * 16 * kc * 2;
-    const dim3 pgrid(N / SK_BN, splits);
+    int NRB, mtiles;
+    skinny_rows(M, &NRB, &mtiles);
+    const bool direct = splits == 1 && mode != 3;          // epilogue in the GEMM launch, no slab
+    const int pmode = direct ? mode : -1;
+    const size_t lds = std::max((size_t)NRB * 16 * kc * 2, (size_t)NRB * 16 * SK_TS * 4);   // A image, then the output tile
+    const dim3 pgrid(N / SK_BN, splits, mtiles);
 #define MGX_SK_PART(R, S)                                                                                          \
     hipLaunchKernelGGL((skinny_partial_kernel<R, S>), pgrid, dim3(256), lds, st, (const bf16_t*)A, (const bf16_t*)Wt, \
-                       workspace, M, N, K)
+                       workspace, bias, (bf16_t*)out, M, N, K, pmode)
 #define MGX_SK_ROWS(S)                                                                                             \
     do {                                                                                                           \
         if (NRB == 1) MGX_SK_PART(1, S);                                                                           \
-        else if (NRB == 4) MGX_SK_PART(4, S);                                                                      \
-        else if (NRB == 8) MGX_SK_PART(8, S);                                                                      \
-        else if (NRB == 12) MGX_SK_PART(12, S);                                                                    \
-        else MGX_SK_PART(16, S);                                                                                   \
+        else if (NRB == 2) MGX_SK_PART(2, S);                                                                      \
+        else if (NRB == 3) MGX_SK_PART(3, S);                                                                      \
+        else MGX_SK_PART(4, S);                                                                                    \
     } while (0)
     if (kc == 64) MGX_SK_ROWS(2);
     else if (kc == 128) MGX_SK_ROWS(4);
     else if (kc == 256) MGX_SK_ROWS(8);
-    else MGX_REQUIRE(false, MGX_EUNSUPPORTED, "mgx_skinny_gemm_bf16: K=%d has no slice depth of 64, 128 or 256", K);
+    else if (kc == 512) MGX_SK_ROWS(16);
+    else if (kc == 1024) MGX_SK_ROWS(32);
+    else MGX_REQUIRE(false, MGX_EUNSUPPORTED, "mgx_skinny_gemm_bf16: K=%d has no slice depth of 64 ... 1024", K);
 #undef MGX_SK_ROWS
 #undef MGX_SK_PART
     MGX_CHECK_LAUNCH("skinny_partial");
+    if (direct) return MGX_OK;
     const long vecs = (long)M * N / 8;
     const dim3 egrid((unsigned)((vecs + 255) / 256));
 #define MGX_SK_RED(MODE)                                                                                           \

@@ -447,7 +447,7 @@ def test_rope_qk_matches_reference_formula_and_inverts(dtype):
 
 
 @pytest.mark.parametrize("M,N,K", [(192, 3072, 1024), (192, 1024, 4096), (3, 1024, 1024), (256, 4096, 1024),
-                                   (50, 128, 192), (17, 64, 64)])
+                                   (50, 128, 192), (17, 64, 64), (100, 256, 2048), (192, 1024, 1024), (65, 8192, 512)])
 @pytest.mark.parametrize("mode", ["bias", "gelu", "relu", "ln"])
 def test_skinny_gemm(M, N, K, mode):
     """Decode projections (mgx_skinny_gemm_bf16) against fp32 torch on the same bf16 operands."""
