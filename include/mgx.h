@@ -176,6 +176,14 @@ int mgx_adamw_multi(int count, float* const* params, const float* const* grads, 
                     float* const* exp_avg_sq, const long* sizes, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int step, float grad_scale, void* stream);
 
+/* bf16 shadows of fp32 master weights (the `.to(x.dtype)` of every autocast projection, and the transposed
+ * operand the GEMM libraries prefer): master [rows, cols] fp32 -> dst [rows, cols] bf16 and/or dst_t
+ * [cols, rows] bf16 in one pass over the master.  `count` matrices per call (HOST arrays of device pointers;
+ * dst[i] or dst_t[i] may be NULL, not both); rows and cols multiples of 64.  Round to nearest even, as
+ * Tensor.to(torch.bfloat16). */
+int mgx_cast_shadow_bf16(int count, const float* const* src, void* const* dst, void* const* dst_t,
+                         const int* rows, const int* cols, void* stream);
+
 /* ---- bf16 MFMA GEMMs for the projections ----------------------------------------------------
  * Replace Conv1d.forward (base_layers.py:54-57) and nn.Linear (alibi_unified.py:90,92) and their
  * autograd GEMMs.  Tile 256x256x64, fp32 accumulate.

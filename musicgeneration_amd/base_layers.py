@@ -9,10 +9,14 @@ Parameters stay fp32 masters; bf16 shadows are cached per parameter version.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
 from . import ops
+
+_PAIRS = os.environ.get("MGX_SHADOW_PAIR", "1") != "0"    # A/B switch: fused two-orientation shadow refresh
 
 
 def generate_square_subsequent_mask(sz, device):
@@ -71,6 +75,38 @@ class ShadowCache:
             self._c[key] = ent
         return ent[1]
 
+    @staticmethod
+    def pair_supported(p: torch.Tensor, dtype, shape) -> bool:
+        return (p.is_cuda and p.dtype == torch.float32 and dtype == torch.bfloat16 and len(shape) == 2
+                and shape[0] % 64 == 0 and shape[1] % 64 == 0)
+
+    def refresh_pairs(self, items, dtype):
+        """items: [(p, shape)] of fp32 masters wanted as bf16 in both orientations.  Every stale pair is rewritten
+        in place by ONE mgx_cast_shadow_bf16 launch (one pass over each master for both copies; the buffers are
+        allocated once), instead of a cast plus a strided transposing copy per weight per optimizer step."""
+        stale = []
+        for p, shape in items:
+            key = (id(p), dtype, "pair")
+            ent = self._c.get(key)
+            if ent is None or ent[1].device != p.device:
+                ent = [-1, torch.empty(shape, dtype=dtype, device=p.device),
+                       torch.empty(shape[::-1], dtype=dtype, device=p.device)]
+                self._c[key] = ent
+            if ent[0] != p._version:
+                stale.append((p, shape, ent))
+        if stale:
+            ops.cast_shadow([p.detach().view(shape) for p, shape, _ in stale], [e[1] for _, _, e in stale],
+                            [e[2] for _, _, e in stale])
+            for p, _, ent in stale:
+                ent[0] = p._version
+
+    def pair(self, p: torch.Tensor, dtype, shape, transposed: bool):
+        ent = self._c.get((id(p), dtype, "pair"))
+        if ent is None or ent[0] != p._version or ent[1].device != p.device:
+            self.refresh_pairs([(p, shape)], dtype)
+            ent = self._c[(id(p), dtype, "pair")]
+        return ent[2] if transposed else ent[1]
+
     def clear(self):
         self._c.clear()
 
@@ -89,39 +125,51 @@ class BlockWeights:
         self.masters = masters
         self.dtype = dtype
         self._c, self._d = cache, d
+        self._shapes = {"wqkv": (d, 3 * d), "wp": (d, d), "w1": tuple(self.m_w1.shape), "w2": tuple(self.m_w2.shape)}
+        ws = [(self.m_wqkv, self._shapes["wqkv"]), (self.m_wp, self._shapes["wp"]), (self.m_w1, self._shapes["w1"]),
+              (self.m_w2, self._shapes["w2"])]
+        self._pairs = _PAIRS and all(cache.pair_supported(p, dtype, shape) for p, shape in ws)
+        if self._pairs:
+            cache.refresh_pairs(ws, dtype)               # the block's four weights, both orientations, one launch
+
+    def _w(self, name, transposed):
+        p, shape = getattr(self, "m_" + name), self._shapes[name]
+        if self._pairs:
+            return self._c.pair(p, self.dtype, shape, transposed)
+        return self._c.get_t(p, self.dtype, shape) if transposed else self._c.get(p, self.dtype, shape)
 
     # [K, N] orientation for x @ W, [N, K] for the NT kernel
     @property
     def wqkv(self):            # [d, 3d]
-        return self._c.get(self.m_wqkv, self.dtype, (self._d, 3 * self._d))
+        return self._w("wqkv", False)
 
     @property
     def wqkv_t(self):          # [3d, d]
-        return self._c.get_t(self.m_wqkv, self.dtype, (self._d, 3 * self._d))
+        return self._w("wqkv", True)
 
     @property
     def wp(self):              # [d, d]
-        return self._c.get(self.m_wp, self.dtype, (self._d, self._d))
+        return self._w("wp", False)
 
     @property
     def wp_t(self):
-        return self._c.get_t(self.m_wp, self.dtype, (self._d, self._d))
+        return self._w("wp", True)
 
     @property
     def w1(self):              # [ff, d]
-        return self._c.get(self.m_w1, self.dtype)
+        return self._w("w1", False)
 
     @property
     def w1_t(self):            # [d, ff]
-        return self._c.get_t(self.m_w1, self.dtype, tuple(self.m_w1.shape))
+        return self._w("w1", True)
 
     @property
     def w2(self):              # [d, ff]
-        return self._c.get(self.m_w2, self.dtype)
+        return self._w("w2", False)
 
     @property
     def w2_t(self):            # [ff, d]
-        return self._c.get_t(self.m_w2, self.dtype, tuple(self.m_w2.shape))
+        return self._w("w2", True)
 
     @property
     def bqkv(self):

@@ -553,6 +553,55 @@ int ln_bwd_launch(const void* dy, const void* dy2, const void* z, const float* m
     return MGX_OK;
 }
 
+
+// ---- bf16 weight shadows ---------------------------------------------------------------------
+// fp32 master [R,C] -> bf16 copy [R,C] and/or bf16 transposed copy [C,R] in ONE pass over the master (the
+// projections want every block weight in both orientations, base_layers.BlockWeights).  64 x 64 tiles through
+// LDS; every global access is a whole 128-byte (bf16) or 256-byte (fp32) row segment.  Multi-tensor: one launch
+// covers up to CAST_MAX matrices (tile index -> matrix by a prefix table passed by value).
+constexpr int CAST_MAX = 16, CAST_LD = 68;
+struct CastMulti {
+    const float* src[CAST_MAX];
+    bf16_t* dst[CAST_MAX];
+    bf16_t* dst_t[CAST_MAX];
+    int rows[CAST_MAX], cols[CAST_MAX];
+    int bstart[CAST_MAX + 1];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void cast_shadow_kernel(CastMulti a) {
+    __shared__ __attribute__((aligned(8))) bf16_t tile[64 * CAST_LD];
+    int i = 0;
+    while (i + 1 < a.count && (int)blockIdx.x >= a.bstart[i + 1]) ++i;
+    const int local = blockIdx.x - a.bstart[i];
+    const int R = a.rows[i], C = a.cols[i];
+    const int tiles_c = C / 64;
+    const int r0 = (local / tiles_c) * 64, c0 = (local % tiles_c) * 64;
+    const float* __restrict__ src = a.src[i];
+    bf16_t* __restrict__ dst = a.dst[i];
+    bf16_t* __restrict__ dst_t = a.dst_t[i];
+    const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 4;
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(src + (long)(r0 + tr + 16 * j) * C + c0 + tc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bf16x4 o = {(bf16_t)v[j][0], (bf16_t)v[j][1], (bf16_t)v[j][2], (bf16_t)v[j][3]};
+        if (dst) *reinterpret_cast<bf16x4*>(dst + (long)(r0 + tr + 16 * j) * C + c0 + tc) = o;
+        *reinterpret_cast<bf16x4*>(tile + (tr + 16 * j) * CAST_LD + tc) = o;
+    }
+    if (!dst_t) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = tr + 16 * j;                       // source column = row of the transposed copy
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = tile[(tc + e) * CAST_LD + c];
+        *reinterpret_cast<bf16x4*>(dst_t + (long)(c0 + c) * R + r0 + tc) = o;
+    }
+}
+
 }  // namespace
 
 extern "C" int mgx_ln_bwd_partial_rows(void) { return PARTIAL_ROWS; }
@@ -678,6 +727,37 @@ extern "C" int mgx_adamw_multi(int count, float* const* params, const float* con
         hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, lr, beta1, beta2, eps,
                            weight_decay, bc1, bc2s, grad_scale);
         MGX_CHECK_LAUNCH("adamw_multi");
+    }
+    return MGX_OK;
+}
+
+extern "C" int mgx_cast_shadow_bf16(int count, const float* const* src, void* const* dst, void* const* dst_t,
+                                    const int* rows, const int* cols, void* stream) {
+    MGX_REQUIRE(count > 0 && src && dst && dst_t && rows && cols, MGX_EINVAL, "mgx_cast_shadow_bf16: null pointer or count=%d", count);
+    hipStream_t st = (hipStream_t)stream;
+    for (int t0 = 0; t0 < count; t0 += CAST_MAX) {
+        CastMulti a;
+        a.count = count - t0 < CAST_MAX ? count - t0 : CAST_MAX;
+        long blocks = 0;
+        for (int i = 0; i < a.count; ++i) {
+            const int t = t0 + i;
+            MGX_REQUIRE(src[t] && (dst[t] || dst_t[t]), MGX_EINVAL, "mgx_cast_shadow_bf16: matrix %d: null source or no destination", t);
+            MGX_REQUIRE(rows[t] > 0 && cols[t] > 0 && rows[t] % 64 == 0 && cols[t] % 64 == 0, MGX_EUNSUPPORTED,
+                        "mgx_cast_shadow_bf16: matrix %d is %d x %d (both must be multiples of 64)", t, rows[t], cols[t]);
+            MGX_REQUIRE((uintptr_t)src[t] % 16 == 0 && (uintptr_t)dst[t] % 8 == 0 && (uintptr_t)dst_t[t] % 8 == 0, MGX_EUNSUPPORTED,
+                        "mgx_cast_shadow_bf16: matrix %d is not aligned (16 B source, 8 B destinations)", t);
+            a.src[i] = src[t];
+            a.dst[i] = (bf16_t*)dst[t];
+            a.dst_t[i] = (bf16_t*)dst_t[t];
+            a.rows[i] = rows[t];
+            a.cols[i] = cols[t];
+            a.bstart[i] = (int)blocks;
+            blocks += (long)(rows[t] / 64) * (cols[t] / 64);
+            MGX_REQUIRE(blocks < (1L << 30), MGX_EUNSUPPORTED, "mgx_cast_shadow_bf16: too many tiles in one launch");
+        }
+        a.bstart[a.count] = (int)blocks;
+        hipLaunchKernelGGL(cast_shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+        MGX_CHECK_LAUNCH("cast_shadow");
     }
     return MGX_OK;
 }

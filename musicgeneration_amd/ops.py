@@ -620,6 +620,33 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, 
                         weight_decay, step, grad_scale, _dt(grad), _stream()), "mgx_adamw")
 
 
+def cast_shadow(srcs, dsts, dsts_t):
+    """bf16 shadows of fp32 matrices in one launch (mgx_cast_shadow_bf16): srcs[i] [R,C] fp32 -> dsts[i] [R,C] bf16
+    and dsts_t[i] [C,R] bf16 (either may be None).  R and C must be multiples of 64."""
+    import ctypes as C
+    n = len(srcs)
+    if not (len(dsts) == len(dsts_t) == n) or n == 0:
+        raise ValueError("cast_shadow: list lengths differ or are empty")
+    for s, d, t in zip(srcs, dsts, dsts_t):
+        _need(s, "src", torch.float32)
+        if s.dim() != 2:
+            raise ValueError("cast_shadow: sources must be 2-D")
+        if d is None and t is None:
+            raise ValueError("cast_shadow: a matrix without destination")
+        if d is not None:
+            _need(d, "dst", torch.bfloat16)
+            if tuple(d.shape) != tuple(s.shape):
+                raise ValueError(f"cast_shadow: dst {tuple(d.shape)} for src {tuple(s.shape)}")
+        if t is not None:
+            _need(t, "dst_t", torch.bfloat16)
+            if tuple(t.shape) != (s.shape[1], s.shape[0]):
+                raise ValueError(f"cast_shadow: dst_t {tuple(t.shape)} for src {tuple(s.shape)}")
+    arr = lambda ts: (C.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+    rows = (C.c_int * n)(*[s.shape[0] for s in srcs])
+    cols = (C.c_int * n)(*[s.shape[1] for s in srcs])
+    check(lib.mgx_cast_shadow_bf16(n, arr(srcs), arr(dsts), arr(dsts_t), rows, cols, _stream()), "mgx_cast_shadow_bf16")
+
+
 def adamw_step_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     """One fused AdamW update over a list of fp32 tensors (mgx_adamw_multi): 1 launch per 32 tensors."""
     import ctypes as C

@@ -557,3 +557,29 @@ def test_gemm_tn_exact_integers():
     b = torch.randint(-3, 4, (K, N), generator=g).float()
     out = ops.gemm_tn(a.bfloat16().cuda(), b.bfloat16().cuda(), torch.float32)
     assert torch.equal(out.cpu(), a.t() @ b)
+
+
+@pytest.mark.parametrize("shapes", [[(64, 64)], [(1024, 3072), (1024, 1024), (4096, 1024), (1024, 4096)],
+                                    [(128, 192)] * 19])
+def test_cast_shadow(shapes):
+    """mgx_cast_shadow_bf16: both bf16 orientations of fp32 masters, bit-exact against Tensor.to / .t().contiguous()
+    (round to nearest even), several matrices per launch, either destination optional."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(len(shapes))
+    srcs = [(torch.randn(r, c, generator=g) * 3).cuda() for r, c in shapes]
+    srcs[0].view(-1)[:4] = torch.tensor([1.00390625, 1.01171875, -0.0, 3.3895e38])     # ties, signed zero, near max
+    dst = [torch.full((r, c), 7.0, dtype=torch.bfloat16).cuda() for r, c in shapes]
+    dst_t = [torch.full((c, r), 7.0, dtype=torch.bfloat16).cuda() for r, c in shapes]
+    ops.cast_shadow(srcs, dst, dst_t)
+    for s, d, t in zip(srcs, dst, dst_t):
+        want = s.to(torch.bfloat16)
+        assert torch.equal(d.view(torch.int16), want.view(torch.int16))
+        assert torch.equal(t.view(torch.int16), want.t().contiguous().view(torch.int16))
+    only_t = [torch.zeros_like(t) for t in dst_t]
+    ops.cast_shadow(srcs, [None] * len(srcs), only_t)
+    only_d = [torch.zeros_like(d) for d in dst]
+    ops.cast_shadow(srcs, only_d, [None] * len(srcs))
+    for a, b in zip(only_t + only_d, dst_t + dst):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    with pytest.raises(RuntimeError):
+        ops.cast_shadow([torch.zeros(60, 64).cuda()], [torch.zeros(60, 64, dtype=torch.bfloat16).cuda()], [None])
