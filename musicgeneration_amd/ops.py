@@ -365,8 +365,10 @@ import os as _os
 
 # bf16 projections.  "mgx": every projection on the hand-written MFMA GEMMs; "torch": every projection a
 # library GEMM (hipBLASLt); "auto" (default): per site, whichever measured faster on MI355X at the
-# training shapes (tools/gemm_bench.py): the MLP up-projection with its fused bias+GELU+dropout epilogue
-# and every weight gradient (TN, split-K, fp32 output) run on libmgx, the rest on the library.
+# training shapes: every weight gradient (TN, split-K, fp32 output) runs on libmgx, the x.W / dy.W^T
+# projections on the library.  The MLP up-projection with its fused bias+GELU+dropout epilogue (gemm_nt_kernel,
+# 412 us) lost the same-box A/B against library GEMM + bias_act_fwd (204 + ~175 us; step 23.88 -> 23.53 ms), so it
+# is no longer an auto site; MGX_AUTO_SITES=mlp1,dwp,dw1,dw2,dwqkv brings it back, MGX_GEMM=mgx runs everything on libmgx.
 GEMM_BACKEND = _os.environ.get("MGX_GEMM", "auto")
 # Operand orientation handed to the library for the projections it runs: "nt" = weight as [N, K] (K contiguous,
 # the transposed shadow where the master is stored [K, N]); "nn" = weight as [K, N]; "native" = whichever
@@ -383,7 +385,7 @@ def _pick(native_is_kn, kn, nk):
     return kn()
 
 
-_AUTO_SITES = {"mlp1", "dwp", "dw1", "dw2", "dwqkv"}
+_AUTO_SITES = frozenset(_os.environ.get("MGX_AUTO_SITES", "dwp,dw1,dw2,dwqkv").split(","))   # A/B switch
 
 
 def _mgx_sites(x2, d, ff):
