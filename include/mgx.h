@@ -176,6 +176,25 @@ int mgx_adamw_multi(int count, float* const* params, const float* const* grads, 
                     float* const* exp_avg_sq, const long* sizes, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int step, float grad_scale, void* stream);
 
+/* ---- head and tail of one greedy sampling step (unified model, bf16) ---------------------------
+ * Replace, around the decoder blocks of one step of inference_unified.py:14-20:
+ *   mgx_decode_gather_embed : seq[:, pos .. pos+R-1] (int32 or int64 rows of length L) -> embedding rows
+ *                             (fp32 table [V,d]) -> out bf16 [B,R,d]   (alibi_unified.py:130-131)
+ *   mgx_decode_head_argmax  : row R-1 of h [B,R,d] bf16 -> Norm (base_layers.py:36-41) -> proj_class W [V,d] bf16,
+ *                             bias fp32 (alibi_unified.py:136-137) -> per-sequence running argmax in keys[B]
+ *                             (uint64, must be 0 on entry; ties -> lowest class, as torch.argmax); logits
+ *                             (optional, may be NULL) [B,V] fp32 receives the bf16-rounded logits
+ *   mgx_decode_commit       : seq[:, pos+1] = argmax class; keys = 0; pos += 1   (inference_unified.py:18-20:
+ *                             token i is drawn from the logits of row i+1)
+ * pos_dev: one int32 in device memory (position of row 0), so a step replays as a HIP graph. */
+int mgx_decode_gather_embed(const void* seq, int seq_is_int64, long L, const int* pos_dev, const float* table,
+                            int V, int d, int B, int R, void* out, void* stream);
+int mgx_decode_head_argmax(const void* h, int B, int R, int d, const float* gamma, const float* beta, float eps,
+                           const void* W, const float* bias, int V, unsigned long long* keys, float* logits,
+                           void* stream);
+int mgx_decode_commit(void* seq, int seq_is_int64, long L, int B, int* pos_dev, unsigned long long* keys,
+                      void* stream);
+
 /* bf16 shadows of fp32 master weights (the `.to(x.dtype)` of every autocast projection, and the transposed
  * operand the GEMM libraries prefer): master [rows, cols] fp32 -> dst [rows, cols] bf16 and/or dst_t
  * [cols, rows] bf16 in one pass over the master.  `count` matrices per call (HOST arrays of device pointers;

@@ -1,0 +1,189 @@
+// Head and tail of one greedy sampling step of the unified model (inference_unified.py:14-20), bf16:
+//   mgx_decode_gather_embed   seq[:, pos .. pos+R-1] -> embedding rows -> bf16 [B,R,d]
+//                             (seq.index_select + F.embedding + .to(dtype): alibi_unified.py:130-131)
+//   mgx_decode_head_argmax    row R-1 of the trunk output -> Norm (base_layers.py:36-41) -> proj_class
+//                             (alibi_unified.py:136-137) -> running argmax per sequence (inference_unified.py:18)
+//   mgx_decode_commit         seq[:, pos+1] = argmax, pos += 1 (inference_unified.py:19-20; the reference draws
+//                             token i from the logits of row i+1)
+// Three launches instead of the ~14 tiny library kernels (index arithmetic, gather, casts, LayerNorm over all
+// rows, a 192 x 618 GEMM, slice, argmax, scatter) that made ~50 us of every 1 ms step.  The position lives in
+// device memory, so the step replays as a HIP graph.  Integer results are exact; logits are the bf16-rounded
+// fp32-accumulated values a bf16 F.linear produces; ties go to the lowest class index as torch.argmax does.
+#include "mgx_common.h"
+
+namespace {
+
+// one workgroup per (b, r) row
+__global__ __launch_bounds__(256) void gather_embed_kernel(const void* __restrict__ seq, int seq_i64, long L,
+                                                            const int* __restrict__ pos, const float* __restrict__ table,
+                                                            int V, int d, int R, bf16_t* __restrict__ out) {
+    const int b = blockIdx.x / R, r = blockIdx.x % R;
+    const long at = (long)b * L + min((long)(*pos + r), L - 1);
+    long tok = seq_i64 ? reinterpret_cast<const long*>(seq)[at] : (long)reinterpret_cast<const int*>(seq)[at];
+    tok = min(max(tok, 0L), (long)V - 1);                 // F.embedding would raise; a sampling buffer never holds these
+    const float* src = table + tok * d;
+    bf16_t* dst = out + (long)blockIdx.x * d;
+    for (int c = threadIdx.x * 4; c < d; c += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+        const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<bf16x4*>(dst + c) = o;
+    }
+}
+
+__device__ __forceinline__ unsigned long long argmax_key(float v, int idx) {
+    unsigned u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // order-preserving map of finite floats to unsigned
+    return ((unsigned long long)u << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)idx);   // ties: the lower index wins
+}
+
+// grid (VC, B), 4 waves.  Every workgroup normalises row R-1 of sequence b itself (d <= 2048 values: cheaper than
+// a launch boundary), then its waves walk the classes of chunk blockIdx.x: one class per wave per pass, the
+// weight row read as two 16-byte loads per lane per 1024 columns.  keys[b] must be 0 on entry (mgx_decode_commit
+// leaves it so).  logits (optional) [B,V] fp32.
+template <int NV>   // d <= 1024 * NV: every thread normalises 4 * NV columns
+__global__ __launch_bounds__(256) void head_argmax_kernel(const bf16_t* __restrict__ h, int R, int d,
+                                                           const float* __restrict__ g, const float* __restrict__ be,
+                                                           float eps, const bf16_t* __restrict__ W,
+                                                           const float* __restrict__ bias, int V, int vper,
+                                                           unsigned long long* __restrict__ keys,
+                                                           float* __restrict__ logits) {
+    __shared__ __attribute__((aligned(16))) bf16_t y[256 * 4 * NV];
+    __shared__ float red[8];
+    __shared__ unsigned long long best[4];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bf16_t* x = h + ((long)b * R + (R - 1)) * d;
+    // LayerNorm as ln_fwd_kernel: fp32 mean, biased variance of the deviations, result rounded to bf16
+    float v[4 * NV];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int col = (c * 256 + tid) * 4;
+        if (col < d) {
+            const bf16x4 t = *reinterpret_cast<const bf16x4*>(x + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[4 * c + e] = (float)t[e];
+                s += v[4 * c + e];
+            }
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int col = (c * 256 + tid) * 4;
+        if (col < d) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = v[4 * c + e] - mu;
+                q = fmaf(t, t, q);
+            }
+        }
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[4 + w] = q;
+    __syncthreads();
+    const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)d + eps);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int col = (c * 256 + tid) * 4;
+        if (col < d) {
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + col);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(be + col);
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)((v[4 * c + e] - mu) * rs * gg[e] + bb[e]);
+            *reinterpret_cast<bf16x4*>(y + col) = o;
+        }
+    }
+    __syncthreads();
+    // classes of this chunk
+    const int v0 = blockIdx.x * vper, v1 = min(v0 + vper, V);
+    unsigned long long mine = 0;
+    for (int cls = v0 + w; cls < v1; cls += 4) {
+        const bf16_t* wr = W + (long)cls * d;
+        float acc = 0.f;
+        for (int col = lane * 8; col < d; col += 512) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(wr + col);
+            const bf16x8 yy = *reinterpret_cast<const bf16x8*>(y + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf((float)a[e], (float)yy[e], acc);
+        }
+        acc = wave_sum(acc);
+        const float lg = (float)(bf16_t)(acc + bias[cls]);
+        if (lane == 0) {
+            if (logits) logits[(long)b * V + cls] = lg;
+            const unsigned long long k = argmax_key(lg, cls);
+            mine = k > mine ? k : mine;
+        }
+    }
+    if (lane == 0) best[w] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long k = best[0];
+        for (int i = 1; i < 4; ++i) k = best[i] > k ? best[i] : k;
+        if (k) atomicMax(keys + b, k);
+    }
+}
+
+// one workgroup: seq[b, pos+1] = class of keys[b]; keys[b] = 0; pos += 1 (after every thread has read it)
+__global__ __launch_bounds__(256) void commit_kernel(void* __restrict__ seq, int seq_i64, long L, int B,
+                                                      int* __restrict__ pos, unsigned long long* __restrict__ keys) {
+    const int p = *pos;
+    __syncthreads();
+    const long at = min((long)p + 1, L - 1);
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const unsigned long long k = keys[b];
+        const long tok = (long)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+        if (seq_i64) reinterpret_cast<long*>(seq)[(long)b * L + at] = tok;
+        else reinterpret_cast<int*>(seq)[(long)b * L + at] = (int)tok;
+        keys[b] = 0;
+    }
+    if (threadIdx.x == 0) *pos = p + 1;
+}
+
+}  // namespace
+
+extern "C" int mgx_decode_gather_embed(const void* seq, int seq_is_int64, long L, const int* pos_dev,
+                                       const float* table, int V, int d, int B, int R, void* out, void* stream) {
+    MGX_REQUIRE(seq && pos_dev && table && out, MGX_EINVAL, "mgx_decode_gather_embed: null pointer");
+    MGX_REQUIRE(B > 0 && R > 0 && L >= R && V > 0, MGX_EINVAL, "mgx_decode_gather_embed: B=%d R=%d L=%ld V=%d", B, R, L, V);
+    MGX_REQUIRE(d > 0 && d % 4 == 0, MGX_EUNSUPPORTED, "mgx_decode_gather_embed: d=%d must be a multiple of 4", d);
+    hipLaunchKernelGGL(gather_embed_kernel, dim3(B * R), dim3(256), 0, (hipStream_t)stream, seq, seq_is_int64, L, pos_dev,
+                       table, V, d, R, (bf16_t*)out);
+    MGX_CHECK_LAUNCH("gather_embed");
+    return MGX_OK;
+}
+
+extern "C" int mgx_decode_head_argmax(const void* h, int B, int R, int d, const float* gamma, const float* beta, float eps,
+                                      const void* W, const float* bias, int V, unsigned long long* keys, float* logits,
+                                      void* stream) {
+    MGX_REQUIRE(h && gamma && beta && W && bias && keys, MGX_EINVAL, "mgx_decode_head_argmax: null pointer");
+    MGX_REQUIRE(B > 0 && R > 0 && V > 0, MGX_EINVAL, "mgx_decode_head_argmax: B=%d R=%d V=%d", B, R, V);
+    MGX_REQUIRE(d >= 8 && d % 8 == 0 && d <= 2048, MGX_EUNSUPPORTED,
+                "mgx_decode_head_argmax: d=%d (multiple of 8, at most 2048)", d);
+    const int VC = V >= 64 ? 8 : 1;                       // class chunks: B x 8 workgroups
+    const int vper = (V + VC - 1) / VC;
+    const dim3 grid(VC, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (d <= 1024)
+        hipLaunchKernelGGL((head_argmax_kernel<1>), grid, dim3(256), 0, st, (const bf16_t*)h, R, d, gamma, beta, eps,
+                           (const bf16_t*)W, bias, V, vper, keys, logits);
+    else
+        hipLaunchKernelGGL((head_argmax_kernel<2>), grid, dim3(256), 0, st, (const bf16_t*)h, R, d, gamma, beta, eps,
+                           (const bf16_t*)W, bias, V, vper, keys, logits);
+    MGX_CHECK_LAUNCH("head_argmax");
+    return MGX_OK;
+}
+
+extern "C" int mgx_decode_commit(void* seq, int seq_is_int64, long L, int B, int* pos_dev, unsigned long long* keys,
+                                 void* stream) {
+    MGX_REQUIRE(seq && pos_dev && keys, MGX_EINVAL, "mgx_decode_commit: null pointer");
+    MGX_REQUIRE(B > 0 && L >= 2, MGX_EINVAL, "mgx_decode_commit: B=%d L=%ld", B, L);
+    hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, seq, seq_is_int64, L, B, pos_dev, keys);
+    MGX_CHECK_LAUNCH("commit");
+    return MGX_OK;
+}

@@ -54,8 +54,17 @@ class KVCacheDecoder:
         execution time (graph replay; R <= 4 only).
         """
         m = self.model
+        h = self.trunk(m.embed_tokens(tokens, self.dtype), pos0)
+        B, R, d = h.shape
+        hn, _, _, _ = ops.ln_residual_fwd(h.reshape(B * R, d), None, m.norm.g, m.norm.b, m.norm.epsilon, save=False)
+        return m.head(hn.view(B, R, d), self._head_wb)
+
+    @torch.no_grad()
+    def trunk(self, h: torch.Tensor, pos0) -> torch.Tensor:
+        """Embedded rows [B,R,d] at positions pos0.. through every decoder block (K/V filed into the caches);
+        returns the last block's output, before the final Norm."""
+        m = self.model
         dt = self.dtype
-        h = m.embed_tokens(tokens, dt)
         B, R, d = h.shape
         if isinstance(pos0, torch.Tensor):
             if R > 4:
@@ -108,8 +117,25 @@ class KVCacheDecoder:
             v = torch.addmm(b2, hact, w2.t())
             h2, _, _, _ = ops.ln_residual_fwd(v, h1, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps, save=False)
             h = h2.view(B, R, d)
-        hn, _, _, _ = ops.ln_residual_fwd(h.reshape(T, d), None, m.norm.g, m.norm.b, m.norm.epsilon, save=False)
-        return m.head(hn.view(B, R, d), self._head_wb)
+        return h
+
+    def fused_greedy_supported(self, seq: torch.Tensor) -> bool:
+        """The three-launch head/tail of a greedy step (csrc/sample.hip): unified model, bf16, d <= 2048."""
+        m = self.model
+        return (os.environ.get("MGX_DECODE_TAIL", "mgx") == "mgx" and self.dtype == torch.bfloat16 and seq.dim() == 2
+                and hasattr(m, "embed") and hasattr(m, "proj_class") and m.d_model % 8 == 0 and m.d_model <= 2048
+                and seq.dtype in (torch.int32, torch.int64) and m.embed.weight.dtype == torch.float32)
+
+    @torch.no_grad()
+    def greedy_step(self, seq: torch.Tensor, pos: torch.Tensor, keys: torch.Tensor):
+        """One step of inference_unified.py:14-20 with deterministic=True, position in device memory: rows pos,
+        pos+1, pos+2 (= i-1, i, i+1) run against the caches, seq[:, pos+1] receives the argmax of the logits of
+        row pos+2, pos advances by one.  keys: zero-initialised int64 [B] scratch."""
+        m = self.model
+        h = ops.decode_gather_embed(seq, pos, m.embed.weight, 3)
+        h = self.trunk(h, pos)
+        ops.decode_head_argmax(h, m.norm.g, m.norm.b, m.norm.epsilon, self._head_wb[0], m.proj_class.bias, keys)
+        ops.decode_commit(seq, pos, keys)
 
 
 class GraphedSampler:
@@ -122,10 +148,13 @@ class GraphedSampler:
     Stochastic sampling keeps the draw outside the graph (generator state is host-side).
     """
 
-    def __init__(self, dec: KVCacheDecoder, seq: torch.Tensor, first: int, deterministic: bool):
+    def __init__(self, dec: KVCacheDecoder, seq: torch.Tensor, first: int, deterministic: bool, capture: bool = True):
         self.dec, self.seq, self.det = dec, seq, deterministic
         self.separated = seq.dim() == 3
         dev = seq.device
+        self.fused = deterministic and dec.fused_greedy_supported(seq)
+        self.keys = torch.zeros(seq.shape[0], dtype=torch.int64, device=dev) if self.fused else None
+        self.graph = None
         self.pos = torch.full((1,), first - 1, dtype=torch.int32, device=dev)   # position of row 0 = i-1
         self.off = torch.arange(3, device=dev)
         self.logits = None
@@ -137,12 +166,16 @@ class GraphedSampler:
             seq.copy_(keep)                      # the warm-up must not leave its token behind: the real
             self.pos.fill_(first - 1)            # first step has to see the stale contents of position i
         torch.cuda.current_stream(dev).wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._body()
+        if capture:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._body()
 
     def _body(self):
         seq = self.seq
+        if self.fused:
+            self.dec.greedy_step(seq, self.pos, self.keys)
+            return
         idx = (self.pos.long() + self.off)                       # i-1, i, i+1
         tok = seq.index_select(-1, idx)
         out = self.dec.rows(tok, self.pos)
@@ -164,7 +197,10 @@ class GraphedSampler:
             seq.index_copy_(1, at, _draw(self.logits, self.det).to(seq.dtype).unsqueeze(-1))
 
     def step(self):
-        self.graph.replay()
+        if self.graph is None:
+            self._body()                         # launch by launch, same kernels
+        else:
+            self.graph.replay()
         if not self.det:
             self._write(at=self.pos.long())      # the graph already advanced the position by one
 
@@ -202,6 +238,11 @@ def sample_next_plus_one(model, seq: torch.Tensor, idx: int = 1, deterministic: 
         if not seq.is_contiguous():
             raise ValueError("seq must be contiguous")
         g = GraphedSampler(dec, seq, idx, deterministic)
+        for _ in steps:
+            g.step()
+        return seq
+    if deterministic and dec.fused_greedy_supported(seq) and seq.is_contiguous() and len(range(idx, L - 1)) > 0:
+        g = GraphedSampler(dec, seq, idx, True, capture=False)     # the graphed step's kernels, launch by launch
         for _ in steps:
             g.step()
         return seq

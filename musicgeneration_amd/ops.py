@@ -554,6 +554,11 @@ def decode_step_attn(qkv, kcache, vcache, slopes, pos0):
         raise ValueError("decode_step_attn shape mismatch")
     out = torch.empty(B, R, H * dh, dtype=qkv.dtype, device=qkv.device)
     if isinstance(pos0, torch.Tensor):
+        if KERNEL_EVENTS is not None and not torch.cuda.is_current_stream_capturing():
+            with _timed("decode_attn"):                  # launch-by-launch pass of bench.py (events cannot be captured)
+                check(lib.mgx_decode_step_attn(_p(qkv), _p(kcache), _p(vcache), _p(slopes), _p(out), B, R, H, dh, Lmax,
+                                               0, _dev_pos(pos0, qkv), _dt(qkv), _stream()), "mgx_decode_step_attn")
+            return out
         check(lib.mgx_decode_step_attn(_p(qkv), _p(kcache), _p(vcache), _p(slopes), _p(out), B, R, H, dh, Lmax, 0,
                                        _dev_pos(pos0, qkv), _dt(qkv), _stream()), "mgx_decode_step_attn")
         return out
@@ -620,6 +625,51 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, 
             raise ValueError("shadow size mismatch")
     check(lib.mgx_adamw(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(shadow), n, lr, beta1, beta2, eps,
                         weight_decay, step, grad_scale, _dt(grad), _stream()), "mgx_adamw")
+
+
+def _seq_args(seq):
+    if seq.dim() != 2 or seq.dtype not in (torch.int32, torch.int64):
+        raise TypeError("seq must be [B, L] int32 or int64")
+    _need(seq, "seq")
+    return _p(seq), int(seq.dtype == torch.int64), seq.shape[1]
+
+
+def decode_gather_embed(seq, pos, table, R=3):
+    """bf16 embedding rows of seq[:, pos .. pos+R-1] (mgx_decode_gather_embed); pos: one int32 on the device."""
+    sp, i64, L = _seq_args(seq)
+    _need(table, "table", torch.float32)
+    V, d = table.shape
+    out = torch.empty(seq.shape[0], R, d, dtype=torch.bfloat16, device=seq.device)
+    check(lib.mgx_decode_gather_embed(sp, i64, L, _dev_pos(pos, seq), _p(table), V, d, seq.shape[0], R, _p(out), _stream()),
+          "mgx_decode_gather_embed")
+    return out
+
+
+def decode_head_argmax(h, gamma, beta, eps, w, bias, keys, logits=None):
+    """Final Norm + output projection + running argmax of row R-1 of h [B,R,d] bf16 into keys [B] (int64 storage of
+    the kernel's uint64 keys, zero on entry); logits: optional fp32 [B,V] receiver."""
+    _need(h, "h", torch.bfloat16)
+    _need(w, "w", torch.bfloat16)
+    for t, n in ((gamma, "gamma"), (beta, "beta"), (bias, "bias")):
+        _need(t, n, torch.float32)
+    _need(keys, "keys", torch.int64)
+    B, R, d = h.shape
+    V = w.shape[0]
+    if w.shape[1] != d or bias.numel() != V or gamma.numel() != d or beta.numel() != d or keys.numel() != B:
+        raise ValueError("decode_head_argmax: shape mismatch")
+    if logits is not None:
+        _need(logits, "logits", torch.float32)
+        if tuple(logits.shape) != (B, V):
+            raise ValueError("decode_head_argmax: logits must be [B, V]")
+    check(lib.mgx_decode_head_argmax(_p(h), B, R, d, _p(gamma), _p(beta), eps, _p(w), _p(bias), V, _p(keys),
+                                     None if logits is None else _p(logits), _stream()), "mgx_decode_head_argmax")
+
+
+def decode_commit(seq, pos, keys):
+    """seq[:, pos+1] = argmax class held in keys; keys = 0; pos += 1 (mgx_decode_commit)."""
+    sp, i64, L = _seq_args(seq)
+    _need(keys, "keys", torch.int64)
+    check(lib.mgx_decode_commit(sp, i64, L, seq.shape[0], _dev_pos(pos, seq), _p(keys), _stream()), "mgx_decode_commit")
 
 
 def cast_shadow(srcs, dsts, dsts_t):

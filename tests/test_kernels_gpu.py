@@ -583,3 +583,50 @@ def test_cast_shadow(shapes):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
     with pytest.raises(RuntimeError):
         ops.cast_shadow([torch.zeros(60, 64).cuda()], [torch.zeros(60, 64, dtype=torch.bfloat16).cuda()], [None])
+
+
+@pytest.mark.parametrize("seq_dtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("B,d,V", [(5, 1024, 618), (64, 1024, 618), (3, 64, 40), (2, 2048, 700)])
+def test_decode_sampling_tail(B, d, V, seq_dtype):
+    """mgx_decode_gather_embed / _head_argmax / _commit (csrc/sample.hip) against the torch ops they replace in one
+    greedy step: gather + embedding + cast (bit-exact), Norm + proj_class logits (bf16 tolerance), argmax with the
+    lowest index on ties (exact on the kernel's own logits), scatter at pos+1 and the position advance (exact)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + d + V)
+    L, R, pos0 = 37, 3, 11
+    seq = torch.randint(0, V, (B, L), generator=g).to(seq_dtype).cuda()
+    table = torch.randn(V, d, generator=g).cuda()
+    pos = torch.tensor([pos0], dtype=torch.int32).cuda()
+    emb = ops.decode_gather_embed(seq, pos, table, R)
+    want = torch.nn.functional.embedding(seq[:, pos0:pos0 + R].long(), table).to(torch.bfloat16)
+    assert torch.equal(emb.view(torch.int16), want.view(torch.int16))
+
+    h = (torch.randn(B, R, d, generator=g) * 2).bfloat16().cuda()
+    gamma, beta = (1 + 0.1 * torch.randn(d, generator=g)).cuda(), (0.1 * torch.randn(d, generator=g)).cuda()
+    w = (torch.randn(V, d, generator=g) / d ** 0.5).bfloat16().cuda()
+    w[7] = w[3]                                               # an exact tie between classes 3 and 7
+    bias = (0.1 * torch.randn(V, generator=g)).cuda()
+    bias[7] = bias[3]
+    keys = torch.zeros(B, dtype=torch.int64).cuda()
+    logits = torch.empty(B, V, dtype=torch.float32).cuda()
+    ops.decode_head_argmax(h, gamma, beta, 1e-5, w, bias, keys, logits)
+    y = torch.nn.functional.layer_norm(h[:, R - 1].float(), (d,), gamma, beta, 1e-5).bfloat16().float()
+    ref = (y @ w.float().t() + bias).bfloat16().float()
+    assert gu.rel_err(logits, ref) < BF16_TOL
+    assert torch.equal(logits[:, 3], logits[:, 7])
+    before = seq.clone()
+    ops.decode_commit(seq, pos, keys)
+    torch.cuda.synchronize()
+    assert int(pos) == pos0 + 1
+    assert torch.equal(seq[:, pos0 + 1].long(), torch.argmax(logits, -1))      # first maximum, as torch
+    keep = torch.ones(L, dtype=torch.bool)
+    keep[pos0 + 1] = False
+    assert torch.equal(seq[:, keep], before[:, keep])
+    assert int(keys.abs().sum()) == 0
+    # the tie itself decides a row: push classes 3 and 7 to the top
+    bias2 = bias.clone()
+    bias2[3] += 100.0
+    bias2[7] += 100.0
+    ops.decode_head_argmax(h, gamma, beta, 1e-5, w, bias2, keys)
+    ops.decode_commit(seq, pos, keys)
+    assert torch.equal(seq[:, pos0 + 2].long().cpu(), torch.full((B,), 3))
