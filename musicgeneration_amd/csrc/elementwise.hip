@@ -479,7 +479,9 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMulti a, float lr,
     const float* __restrict__ g = a.g[t];
     float* __restrict__ m = a.m[t];
     float* __restrict__ v = a.v[t];
-    const bool vec = (n & 3) == 0;                                               // 16-byte rows (tensors are 256-B aligned)
+    // 16-byte accesses only when every tensor allows them (gradients can be views at odd offsets, e.g. the slices
+    // of a fused [d, 92+130+203] head gradient)
+    const bool vec = (n & 3) == 0 && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
 #pragma unroll
     for (int q = 0; q < ADAM_CHUNK / 1024; ++q) {
         const long i = base + q * 1024 + threadIdx.x * 4;
@@ -712,8 +714,8 @@ extern "C" int mgx_adamw_multi(int count, float* const* params, const float* con
             const int t = t0 + i;
             MGX_REQUIRE(params[t] && grads[t] && exp_avg[t] && exp_avg_sq[t] && sizes[t] > 0, MGX_EINVAL,
                         "mgx_adamw_multi: tensor %d: null pointer or empty", t);
-            MGX_REQUIRE(((uintptr_t)params[t] | (uintptr_t)grads[t] | (uintptr_t)exp_avg[t] | (uintptr_t)exp_avg_sq[t]) % 16 == 0,
-                        MGX_EUNSUPPORTED, "mgx_adamw_multi: tensor %d is not 16-byte aligned", t);
+            MGX_REQUIRE(((uintptr_t)params[t] | (uintptr_t)grads[t] | (uintptr_t)exp_avg[t] | (uintptr_t)exp_avg_sq[t]) % 4 == 0,
+                        MGX_EUNSUPPORTED, "mgx_adamw_multi: tensor %d is not 4-byte aligned", t);
             a.p[i] = params[t];
             a.g[i] = grads[t];
             a.m[i] = exp_avg[t];

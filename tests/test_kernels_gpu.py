@@ -422,7 +422,14 @@ def test_adamw_multi_matches_torch():
         for r, gr in zip(refs, grads):
             r.grad = gr.clone()
         opt.step()
-        ops.adamw_step_multi(ps, [gr.cuda() for gr in grads], ms, vs, 1e-3, 0.9, 0.999, 1e-8, 1e-4, step)
+        # gradients as views at odd element offsets of one buffer (the slices of a fused-head gradient look like
+        # this): the kernel must not assume 16-byte alignment
+        flat = torch.empty(sum(sizes) + len(sizes), device="cuda")
+        gv, off = [], 1
+        for n, gr in zip(sizes, grads):
+            gv.append(flat[off:off + n].copy_(gr))
+            off += n + 1
+        ops.adamw_step_multi(ps, gv, ms, vs, 1e-3, 0.9, 0.999, 1e-8, 1e-4, step)
     for p, r in zip(ps, refs):
         assert float((p.cpu() - r.detach()).abs().max()) < 1e-6
 

@@ -116,6 +116,30 @@ def test_separated_fp32():
     assert abs(float(loss2) - float(z["loss"])) < 1e-5 * abs(float(z["loss"]))
 
 
+def test_separated_fused_adamw_matches_torch_adamw():
+    """Two optimizer steps of the separated model: FusedAdamW (multi-tensor kernel; the three head gradients are
+    odd-offset slices of one fused [d, 92+130+203] gradient) against torch.optim.AdamW on the same gradients."""
+    from musicgeneration_amd.model_baseline.alibi_separated import AlibiTransformer, Criterion
+    from musicgeneration_amd.optim import FusedAdamW
+    z = gu.load("separated_tiny")
+    x, y = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["y"]).cuda()
+    finals = []
+    for opt_cls in (torch.optim.AdamW, FusedAdamW):
+        m = AlibiTransformer(92, 130, 203, 16, 16, 32, 2, 8, 64, 128, dropout=0.0)
+        m.load_state_dict(gu.state_dict(z))
+        m = m.cuda()
+        crit = Criterion(92, 130, 203, {"loss_notes": 1, "loss_velocity": 0.5, "loss_duration": 2}).cuda()
+        opt = opt_cls(m.parameters(), lr=1e-3, weight_decay=1e-4)
+        for _ in range(2):
+            loss, _ = crit(m(x), y)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        finals.append({k: v.detach().clone() for k, v in m.state_dict().items()})
+    for k, v in finals[0].items():
+        assert float((finals[1][k] - v).abs().max()) < 2e-6, k
+
+
 @pytest.mark.parametrize("S", [48, 64])
 def test_relative_fp32(S):
     from musicgeneration_amd.old_models.relative_transformer import RelativeTransformer
