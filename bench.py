@@ -216,6 +216,8 @@ def main():
     # object is the one with the largest total time.  achieved = algorithmic FLOPs of the launches / their time.
     labels = {"alibi_attn_fwd": "attn_fwd_mfma_kernel (ALiBi flash forward; QK^T + PV at half the square)",
               "rel_attn_fwd": "rel_fwd_mfma_kernel (skew relative flash forward; QK^T + QE^T + PV at half the square)",
+              "rel_attn_bwd": "rel_bwd_dkv + rel_bwd_dq + rel_bwd_de + delta (6 products at half the square; 16 executed: "
+                              "S, dP and Q.E^T are recomputed in each of the three kernels)",
               "alibi_attn_bwd": "attn_bwd_dkv_mfma_kernel + attn_bwd_dq_mfma_kernel + delta (5 products at half the square)",
               "gemm_nt": "gemm_nt_kernel (MLP up-projection with bias + GELU + dropout epilogue)",
               "gemm_tn": "gemm_tn_kernel + splitk_reduce_kernel (weight gradients, split-K fp32 slabs)"}

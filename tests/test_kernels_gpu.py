@@ -154,7 +154,7 @@ def test_relative_attention(B, S, H, dh, M, dtype):
 
 
 @pytest.mark.parametrize("B,S,H,dh,M", [(2, 150, 2, 64, 160), (1, 600, 3, 64, 640), (2, 257, 2, 128, 264),
-                                         (1, 384, 2, 64, 384), (1, 31, 1, 64, 32), (1, 129, 2, 128, 1024)])
+                                         (1, 384, 2, 64, 384), (1, 31, 1, 64, 32), (1, 129, 2, 128, 1024), (3, 200, 2, 64, 256), (5, 96, 1, 64, 128)])
 @pytest.mark.parametrize("force_generic", [False, True])
 def test_relative_attention_bf16_mfma(B, S, H, dh, M, force_generic):
     """Skew relative attention on the MFMA path (ring skew through LDS, dE band kernel) and on the
