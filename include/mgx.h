@@ -101,6 +101,7 @@ int mgx_ln_residual_bwd(const void* dy, const void* dy2, const void* z, const fl
  * Replaces `drop(activation(linear1(x)))`'s elementwise tail (alibi_unified.py:90-91):
  *   u [T,n] GEMM output WITHOUT bias; bias [n] fp32
  *   pre [T,n] = u + bias (kept for the backward; may alias u), h [T,n] = drop(act(pre))
+ *   bias == NULL and pre == NULL: u already is the pre-activation (a GEMM epilogue added the bias); only h is written
  * act: MGX_ACT_GELU is the exact erf form (F.gelu default), MGX_ACT_RELU for the relative model.
  */
 int mgx_bias_act_fwd(const void* u, const float* bias, void* pre, void* h,

@@ -180,6 +180,10 @@ class BlockWeights:
         return self._c.get(self.m_bp, self.dtype)
 
     @property
+    def b1(self):
+        return self._c.get(self.m_b1, self.dtype)
+
+    @property
     def b2(self):
         return self._c.get(self.m_b2, self.dtype)
 

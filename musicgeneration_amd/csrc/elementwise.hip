@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const T* __restrict__
     for (int col = threadIdx.x * N; col < n; col += 256 * N) {
         float bv[N];
 #pragma unroll
-        for (int k = 0; k < N; ++k) bv[k] = bias[col + k];
+        for (int k = 0; k < N; ++k) bv[k] = bias ? bias[col + k] : 0.f;     // bias == NULL: u already is the pre-activation
         for (long row0 = blockIdx.x; row0 < T_rows; row0 += (long)U * gridDim.x) {
             float v[U][N];
 #pragma unroll
@@ -644,7 +644,7 @@ extern "C" int mgx_ln_residual_bwd(const void* dy, const void* dy2, const void* 
 
 extern "C" int mgx_bias_act_fwd(const void* u, const float* bias, void* pre, void* h, long T, int n, int act,
                                 float p_drop, unsigned long long seed, int dtype, void* stream) {
-    MGX_REQUIRE(u && bias && h, MGX_EINVAL, "mgx_bias_act_fwd: null pointer");
+    MGX_REQUIRE(u && h, MGX_EINVAL, "mgx_bias_act_fwd: null pointer");
     MGX_REQUIRE(T > 0 && n > 0, MGX_EINVAL, "mgx_bias_act_fwd: T=%ld n=%d", T, n);
     MGX_REQUIRE(dtype == MGX_F32 || dtype == MGX_BF16, MGX_EINVAL, "mgx_bias_act_fwd: bad dtype %d", dtype);
     MGX_REQUIRE(act == MGX_ACT_GELU || act == MGX_ACT_RELU, MGX_EINVAL, "mgx_bias_act_fwd: bad act %d", act);

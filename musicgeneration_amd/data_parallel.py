@@ -48,6 +48,7 @@ class GradientBucketer:
         # identical replicas: broadcast rank 0's weights once
         for p in model.parameters():
             dist.broadcast(p.data, src=0, group=process_group)
+            torch.autograd.graph.increment_version(p)    # written through .data: version-keyed weight shadows must refresh
         for b in model.buffers():
             dist.broadcast(b.data, src=0, group=process_group)
 

@@ -208,18 +208,23 @@ def ln_residual_bwd(dy, dy2, z, mean, rstd, gamma, p_drop=0.0, seed=0, want_dsum
 # bias + activation (+ dropout)
 # ---------------------------------------------------------------------------
 def bias_act_fwd(u, bias, act="gelu", p_drop=0.0, seed=0, inplace_pre=True):
-    """(pre, h) with pre = u + bias (written over u when inplace_pre) and h = dropout(act(pre))."""
+    """(pre, h) with pre = u + bias (written over u when inplace_pre) and h = dropout(act(pre)).
+    bias=None: u already is the pre-activation (a GEMM with a bias epilogue produced it); it is returned as pre
+    untouched and only h is written (one pass less over [T, n])."""
     _need(u, "u")
-    _need(bias, "bias", torch.float32)
     n = u.shape[-1]
     T = u.numel() // n
-    if bias.numel() != n:
-        raise ValueError("bias size mismatch")
-    pre = u if inplace_pre else torch.empty_like(u)
+    if bias is None:
+        pre = None
+    else:
+        _need(bias, "bias", torch.float32)
+        if bias.numel() != n:
+            raise ValueError("bias size mismatch")
+        pre = u if inplace_pre else torch.empty_like(u)
     h = torch.empty_like(u)
     check(lib.mgx_bias_act_fwd(_p(u), _p(bias), _p(pre), _p(h), T, n, _ACT[act], float(p_drop), seed, _dt(u), _stream()),
           "mgx_bias_act_fwd")
-    return pre, h
+    return (u if bias is None else pre), h
 
 
 def bias_act_bwd(dh, pre, act="gelu", p_drop=0.0, seed=0):
@@ -386,6 +391,7 @@ def _pick(native_is_kn, kn, nk):
     return kn()
 
 
+_MLP1_BIAS_IN_GEMM = _os.environ.get("MGX_MLP1_BIAS", "gemm") == "gemm"     # A/B switch
 _AUTO_SITES = frozenset(_os.environ.get("MGX_AUTO_SITES", "dwp,dw1,dw2,dwqkv").split(","))   # A/B switch
 
 
@@ -436,8 +442,14 @@ class _DecoderBlock(torch.autograd.Function):
         if "mlp1" in mgx:
             pre, hact = gemm_nt(h1, W.w1, W.m_b1, None, act, p, seed2)
         else:
-            u = torch.mm(h1, _pick(False, lambda: W.w1_t, lambda: W.w1))
-            pre, hact = bias_act_fwd(u, W.m_b1, act, p, seed2)
+            # bias in the library GEMM's epilogue (bf16 bias, as autocast's F.linear), then activation + dropout
+            # only: two passes over [T, ff] instead of three
+            if _MLP1_BIAS_IN_GEMM:
+                pre = torch.addmm(W.b1, h1, _pick(False, lambda: W.w1_t, lambda: W.w1))
+                _, hact = bias_act_fwd(pre, None, act, p, seed2)
+            else:
+                u = torch.mm(h1, _pick(False, lambda: W.w1_t, lambda: W.w1))
+                pre, hact = bias_act_fwd(u, W.m_b1, act, p, seed2)
         v = (gemm_nt(hact, W.w2, W.m_b2) if "mlp2" in mgx
              else torch.addmm(W.b2, hact, _pick(False, lambda: W.w2_t, lambda: W.w2)))
         h2, z2, mean2, rstd2 = ln_residual_fwd(v, h1, W.m_g2, W.m_be2, eps)
