@@ -492,7 +492,9 @@ class _DecoderBlock(torch.autograd.Function):
         if "dx" in mgx:
             dx = gemm_nt(dqkv2, W.wqkv, None, dz1).view(B, S, d)                        # dqkv @ wqkv^T + dz1
         else:
-            dx = torch.addmm(dz1, dqkv2, _pick(False, lambda: W.wqkv_t, lambda: W.wqkv)).view(B, S, d)
+            # in place: out-of-place addmm first copies dz1 (67 MB) into its result.  dz1 (and da1, which aliases it
+            # without dropout) has no reader after this point
+            dx = dz1.addmm_(dqkv2, _pick(False, lambda: W.wqkv_t, lambda: W.wqkv)).view(B, S, d)
         return (dx, None, None, dE, None, None,
                 dwqkv.unsqueeze(0), dbqkv, dwp.unsqueeze(0), dbp, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2)
 
