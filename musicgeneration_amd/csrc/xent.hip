@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int XENT_PARTIALS = 256;
+constexpr int XENT_PARTIALS = 2048;   // forward blocks (4 rows in flight each): 8 per CU; 256 left one wave per SIMD (155 us at T = 32768)
 
 template <typename T>
 __global__ __launch_bounds__(256) void xent_fwd_kernel(const T* __restrict__ logits, const long long* __restrict__ tgt,
