@@ -196,6 +196,12 @@ int mgx_decode_head_argmax(const void* h, int B, int R, int d, const float* gamm
 int mgx_decode_commit(void* seq, int seq_is_int64, long L, int B, int* pos_dev, unsigned long long* keys,
                       void* stream);
 
+/* Column sums of a bf16 matrix x [T,n] -> out [n] fp32: the bias gradient of a projection whose output gradient no
+ * other kernel of the block reduces (c_attn: dqkv.sum(0), autograd of alibi_unified.py:59 / base_layers.py:54-57).
+ * workspace: mgx_colsum_workspace_floats(n) floats.  Fixed summation order (deterministic). */
+long mgx_colsum_workspace_floats(int n);
+int mgx_colsum_bf16(const void* x, float* out, float* workspace, long T, int n, void* stream);
+
 /* bf16 shadows of fp32 master weights (the `.to(x.dtype)` of every autocast projection, and the transposed
  * operand the GEMM libraries prefer): master [rows, cols] fp32 -> dst [rows, cols] bf16 and/or dst_t
  * [cols, rows] bf16 in one pass over the master.  `count` matrices per call (HOST arrays of device pointers;

@@ -604,6 +604,55 @@ __global__ __launch_bounds__(256) void cast_shadow_kernel(CastMulti a) {
     }
 }
 
+
+// ---- column sums of a bf16 matrix (bias gradient of c_attn: dqkv.sum(0), alibi_unified.py:59) ----
+// stage 1: grid (n / 512, COLSUM_CHUNKS): a workgroup adds up its share of the rows for 512 columns (16-byte loads,
+// 8 columns per lane, fp32 accumulation, 8 loads in flight per lane); stage 2: one thread per column adds the
+// COLSUM_CHUNKS partials in a fixed order.  Deterministic, no atomics.
+constexpr int COLSUM_CHUNKS = 128;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial,
+                                                              long T_rows, int n) {
+    __shared__ float red[3][512];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = blockIdx.x * 512 + lane * 8;
+    const long per = (T_rows + COLSUM_CHUNKS - 1) / COLSUM_CHUNKS;
+    const long r0 = (long)blockIdx.y * per, r1 = min(r0 + per, T_rows);
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    if (col < n) {
+        for (long r = r0 + w; r < r1; r += 32) {
+            bf16x8 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const bf16x8*>(x + min(r + 4 * q, r1 - 1) * n + col);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (r + 4 * q < r1) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] += (float)v[q][k];
+                }
+        }
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[w - 1][lane * 8 + k] = acc[k];
+    }
+    __syncthreads();
+    if (w == 0 && col < n) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            partial[(long)blockIdx.y * n + col + k] = ((acc[k] + red[0][lane * 8 + k]) + red[1][lane * 8 + k]) + red[2][lane * 8 + k];
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int n) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < COLSUM_CHUNKS; ++p) s += partial[(long)p * n + c];
+    out[c] = s;
+}
+
 }  // namespace
 
 extern "C" int mgx_ln_bwd_partial_rows(void) { return PARTIAL_ROWS; }
@@ -761,5 +810,19 @@ extern "C" int mgx_cast_shadow_bf16(int count, const float* const* src, void* co
         hipLaunchKernelGGL(cast_shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
         MGX_CHECK_LAUNCH("cast_shadow");
     }
+    return MGX_OK;
+}
+
+extern "C" long mgx_colsum_workspace_floats(int n) { return n > 0 ? (long)COLSUM_CHUNKS * n : 0; }
+
+extern "C" int mgx_colsum_bf16(const void* x, float* out, float* workspace, long T, int n, void* stream) {
+    MGX_REQUIRE(x && out && workspace, MGX_EINVAL, "mgx_colsum_bf16: null pointer");
+    MGX_REQUIRE(T > 0 && n > 0 && n % 8 == 0, MGX_EUNSUPPORTED, "mgx_colsum_bf16: T=%ld n=%d (n must be a multiple of 8)", T, n);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((n + 511) / 512, COLSUM_CHUNKS), dim3(256), 0, st, (const bf16_t*)x,
+                       workspace, T, n);
+    MGX_CHECK_LAUNCH("colsum_partial");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((n + 255) / 256), dim3(256), 0, st, workspace, out, n);
+    MGX_CHECK_LAUNCH("colsum_final");
     return MGX_OK;
 }

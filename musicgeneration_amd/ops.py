@@ -487,7 +487,7 @@ class _DecoderBlock(torch.autograd.Function):
         if rope is not None:
             rope_qk_(dqkv, rope[0], rope[1], n_heads, inverse=True)
         dqkv2 = dqkv.view(T, 3 * d)
-        dbqkv = dqkv2.sum(0, dtype=f32)
+        dbqkv = colsum(dqkv2) if dqkv2.dtype == torch.bfloat16 and (3 * d) % 8 == 0 else dqkv2.sum(0, dtype=f32)
         dwqkv = gemm_tn(x2, dqkv2) if "dwqkv" in mgx else torch.mm(x2.t(), dqkv2)       # [d, 3d]
         if "dx" in mgx:
             dx = gemm_nt(dqkv2, W.wqkv, None, dz1).view(B, S, d)                        # dqkv @ wqkv^T + dz1
@@ -685,6 +685,16 @@ def decode_commit(seq, pos, keys):
     sp, i64, L = _seq_args(seq)
     _need(keys, "keys", torch.int64)
     check(lib.mgx_decode_commit(sp, i64, L, seq.shape[0], _dev_pos(pos, seq), _p(keys), _stream()), "mgx_decode_commit")
+
+
+def colsum(x):
+    """fp32 column sums of a bf16 matrix [T, n] (mgx_colsum_bf16), fixed summation order."""
+    _need(x, "x", torch.bfloat16)
+    T, n = x.shape
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    ws = torch.empty(int(lib.mgx_colsum_workspace_floats(n)), dtype=torch.float32, device=x.device)
+    check(lib.mgx_colsum_bf16(_p(x), _p(out), _p(ws), T, n, _stream()), "mgx_colsum_bf16")
+    return out
 
 
 def cast_shadow(srcs, dsts, dsts_t):

@@ -637,3 +637,15 @@ def test_decode_sampling_tail(B, d, V, seq_dtype):
     ops.decode_head_argmax(h, gamma, beta, 1e-5, w, bias2, keys)
     ops.decode_commit(seq, pos, keys)
     assert torch.equal(seq[:, pos0 + 2].long().cpu(), torch.full((B,), 3))
+
+
+@pytest.mark.parametrize("T,n", [(32768, 3072), (1000, 1544), (5, 8), (129, 512), (4097, 520)])
+def test_colsum(T, n):
+    """mgx_colsum_bf16 against an fp64 column sum of the same bf16 values; run twice for bitwise reproducibility."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(T + n)
+    x = torch.randn(T, n, generator=g).bfloat16().cuda()
+    got = ops.colsum(x)
+    ref = x.double().sum(0)
+    assert float((got.double() - ref).abs().max()) < 1e-4 * max(1.0, T ** 0.5)
+    assert torch.equal(got, ops.colsum(x))
