@@ -424,3 +424,22 @@ def test_rotary_intended_rotation_vs_oracle():
             assert float(p.grad.abs().max()) < 1e-7, k
             continue
         assert gu.rel_err(p.grad, osd[k].grad) < 2e-5, k
+
+
+def test_bench_data_parallel_path_on_rccl():
+    """bench.py's data-parallel step (RCCL process group, GradientBucketer: side-stream all-reduce from the grad
+    hooks, join before the optimizer) with one rank on this GPU, against the plain single-GPU step: same seeds,
+    same batches -> the same loss after 3 steps (averaging over a world of one is the identity)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--seq", "512",
+           "--no-cpu-baseline"]
+    lines = []
+    for force in ("0", "1"):
+        env = dict(os.environ, MGX_BENCH_FORCE_DP=force, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    assert lines[0]["n_gpus"] == lines[1]["n_gpus"] == 1
+    assert np.isfinite(lines[1]["final_loss"])
+    assert abs(lines[0]["final_loss"] - lines[1]["final_loss"]) < 2e-2      # dropout masks are seeded; bf16 step
