@@ -6,8 +6,9 @@ for MI355X's point-to-point xGMI (7 links x ~153 GB/s per GPU): parameters are
 packed into ~32 MB buckets in reverse forward order; a bucket's all-reduce is
 issued on a side stream from the autograd hook of its last-arriving gradient,
 so the exchange of layer k hides under the backward GEMMs of layers < k.
-Gradients are averaged (sum / world).  `finish()` joins the side stream before
-the optimizer step.  Works on CPU with gloo for tests (no streams there).
+Gradients are averaged (RCCL's AVG; sum / world on gloo) in persistent flat
+buffers whose slots become p.grad afterwards (no scatter copies).  `finish()`
+joins the side stream before the optimizer step.  Works on CPU with gloo for tests (no streams there).
 """
 from __future__ import annotations
 
@@ -27,6 +28,8 @@ class GradientBucketer:
         self.params = params
         self.cuda = params[0].is_cuda
         self.stream = torch.cuda.Stream() if self.cuda else None
+        # NCCL/RCCL averages in the collective; gloo has no AVG: pre-divide there
+        self.avg = self.cuda and dist.get_backend(process_group) == "nccl"
         limit = int(bucket_mb * 1024 * 1024)
         self.buckets: List[List[torch.nn.Parameter]] = []
         cur, size = [], 0
@@ -39,10 +42,24 @@ class GradientBucketer:
             size += nbytes
         if cur:
             self.buckets.append(cur)
+        # one persistent flat buffer per bucket, every parameter's slot 16-byte aligned; after the exchange
+        # p.grad IS its slot (a view): no scatter copies, and the fused optimizer keeps its vector loads
+        self._flat, self._views = [], []
+        for ps in self.buckets:
+            dt = ps[0].dtype
+            if any(p.dtype != dt for p in ps):
+                raise ValueError("a gradient bucket must hold one dtype")
+            pad = max(1, 16 // ps[0].element_size())
+            offs, off = [], 0
+            for p in ps:
+                offs.append(off)
+                off += (p.numel() + pad - 1) // pad * pad
+            flat = torch.zeros(off, dtype=dt, device=ps[0].device)
+            self._flat.append(flat)
+            self._views.append([flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, ps)])
         self._bucket_of = {id(p): b for b, ps in enumerate(self.buckets) for p in ps}
         self._pending = [len(b) for b in self.buckets]
         self._work = []
-        self._flat = [None] * len(self.buckets)
         for p in params:
             p.register_post_accumulate_grad_hook(self._hook)
         # identical replicas: broadcast rank 0's weights once
@@ -58,25 +75,27 @@ class GradientBucketer:
         if self._pending[b] == 0:
             self._launch(b)
 
+    def _exchange(self, b):
+        ps, flat = self.buckets[b], self._flat[b]
+        torch._foreach_copy_(self._views[b], [p.grad for p in ps])      # one multi-tensor launch
+        if self.avg:
+            return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        flat.div_(self.world)
+        return dist.all_reduce(flat, group=self.group, async_op=True)
+
     def _launch(self, b):
-        ps = self.buckets[b]
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                flat = torch.cat([p.grad.reshape(-1) for p in ps])
-                flat.div_(self.world)
-                work = dist.all_reduce(flat, group=self.group, async_op=True)
-                for p in ps:
+                work = self._exchange(b)
+                for p in self.buckets[b]:
                     p.grad.record_stream(self.stream)
         else:
-            flat = torch.cat([p.grad.reshape(-1) for p in ps])
-            flat.div_(self.world)
-            work = dist.all_reduce(flat, group=self.group, async_op=True)
-        self._flat[b] = flat
+            work = self._exchange(b)
         self._work.append((b, work))
 
     def finish(self):
-        """Wait for every bucket, scatter the averaged values back into p.grad."""
+        """Wait for every bucket; p.grad becomes the parameter's slot of the averaged flat buffer."""
         for b, n in enumerate(self._pending):
             if n != 0 and n != len(self.buckets[b]):
                 raise RuntimeError("some parameters of a bucket received no gradient")
@@ -86,15 +105,11 @@ class GradientBucketer:
             ctx = torch.cuda.stream(self.stream) if self.cuda else _null()
             with ctx:
                 work.wait()                              # orders the side stream after the collective
-                off = 0
-                for p in self.buckets[b]:
-                    n = p.numel()
-                    p.grad.copy_(self._flat[b][off:off + n].view_as(p.grad))
-                    off += n
+            for p, v in zip(self.buckets[b], self._views[b]):
+                p.grad = v
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
         self._work.clear()
-        self._flat = [None] * len(self.buckets)
         self._pending = [len(b) for b in self.buckets]
 
 
