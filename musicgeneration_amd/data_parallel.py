@@ -12,6 +12,7 @@ joins the side stream before the optimizer step.  Works on CPU with gloo for tes
 """
 from __future__ import annotations
 
+import os
 from typing import List
 
 import torch
@@ -30,6 +31,11 @@ class GradientBucketer:
         self.stream = torch.cuda.Stream() if self.cuda else None
         # NCCL/RCCL averages in the collective; gloo has no AVG: pre-divide there
         self.avg = self.cuda and dist.get_backend(process_group) == "nccl"
+        # "inplace" (RCCL only): a bucket is ONE grouped all-reduce over the gradient tensors where they lie
+        # (ncclGroupStart/End through c10d's coalescing manager): no flat copy in either direction.  "flat": the
+        # gradients are packed into a persistent flat buffer first (any backend).
+        mode = os.environ.get("MGX_DP_MODE", "inplace")
+        self.inplace = self.avg and mode == "inplace" and hasattr(dist, "_coalescing_manager")
         limit = int(bucket_mb * 1024 * 1024)
         self.buckets: List[List[torch.nn.Parameter]] = []
         cur, size = [], 0
@@ -42,6 +48,22 @@ class GradientBucketer:
             size += nbytes
         if cur:
             self.buckets.append(cur)
+        self._flat, self._views = [], []
+        if not self.inplace:
+            self._alloc_flat()
+        self._bucket_of = {id(p): b for b, ps in enumerate(self.buckets) for p in ps}
+        self._pending = [len(b) for b in self.buckets]
+        self._work = []
+        for p in params:
+            p.register_post_accumulate_grad_hook(self._hook)
+        # identical replicas: broadcast rank 0's weights once
+        for p in model.parameters():
+            dist.broadcast(p.data, src=0, group=process_group)
+            torch.autograd.graph.increment_version(p)    # written through .data: version-keyed weight shadows must refresh
+        for b in model.buffers():
+            dist.broadcast(b.data, src=0, group=process_group)
+
+    def _alloc_flat(self):
         # one persistent flat buffer per bucket, every parameter's slot 16-byte aligned; after the exchange
         # p.grad IS its slot (a view): no scatter copies, and the fused optimizer keeps its vector loads
         self._flat, self._views = [], []
@@ -57,17 +79,6 @@ class GradientBucketer:
             flat = torch.zeros(off, dtype=dt, device=ps[0].device)
             self._flat.append(flat)
             self._views.append([flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, ps)])
-        self._bucket_of = {id(p): b for b, ps in enumerate(self.buckets) for p in ps}
-        self._pending = [len(b) for b in self.buckets]
-        self._work = []
-        for p in params:
-            p.register_post_accumulate_grad_hook(self._hook)
-        # identical replicas: broadcast rank 0's weights once
-        for p in model.parameters():
-            dist.broadcast(p.data, src=0, group=process_group)
-            torch.autograd.graph.increment_version(p)    # written through .data: version-keyed weight shadows must refresh
-        for b in model.buffers():
-            dist.broadcast(b.data, src=0, group=process_group)
 
     def _hook(self, p):
         b = self._bucket_of[id(p)]
@@ -83,7 +94,24 @@ class GradientBucketer:
         flat.div_(self.world)
         return dist.all_reduce(flat, group=self.group, async_op=True)
 
+    def _exchange_inplace(self, b):
+        with dist._coalescing_manager(group=self.group, async_ops=True) as cm:
+            for p in self.buckets[b]:
+                dist.all_reduce(p.grad, op=dist.ReduceOp.AVG, group=self.group)
+        return cm
+
     def _launch(self, b):
+        if self.inplace:
+            # c10d orders its RCCL stream after the current stream (the gradients' producer) at the call and the
+            # caller's stream after the collective at wait(): no side stream, no copies
+            try:
+                self._work.append((b, self._exchange_inplace(b)))
+                return
+            except (RuntimeError, ValueError, AttributeError, TypeError):
+                if self._work:
+                    raise                                    # earlier buckets of this step already went in place
+                self.inplace = False                         # this torch build cannot group them: pack instead
+                self._alloc_flat()
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
@@ -101,14 +129,18 @@ class GradientBucketer:
                 raise RuntimeError("some parameters of a bucket received no gradient")
             if n == len(self.buckets[b]) and any(p.grad is not None for p in self.buckets[b]):
                 raise RuntimeError("bucket bookkeeping out of sync")
-        for b, work in self._work:
-            ctx = torch.cuda.stream(self.stream) if self.cuda else _null()
-            with ctx:
-                work.wait()                              # orders the side stream after the collective
-            for p, v in zip(self.buckets[b], self._views[b]):
-                p.grad = v
-        if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.stream)
+        if self.inplace:
+            for b, work in self._work:
+                work.wait()                              # orders the current stream after the collective
+        else:
+            for b, work in self._work:
+                ctx = torch.cuda.stream(self.stream) if self.cuda else _null()
+                with ctx:
+                    work.wait()                          # orders the side stream after the collective
+                for p, v in zip(self.buckets[b], self._views[b]):
+                    p.grad = v
+            if self.cuda:
+                torch.cuda.current_stream().wait_stream(self.stream)
         self._work.clear()
         self._pending = [len(b) for b in self.buckets]
 
