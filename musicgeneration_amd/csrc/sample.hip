@@ -37,7 +37,7 @@ __device__ __forceinline__ unsigned long long argmax_key(float v, int idx) {
 }
 
 // grid (VC, B), 4 waves.  Every workgroup normalises row R-1 of sequence b itself (d <= 2048 values: cheaper than
-// a launch boundary), then its waves walk the classes of chunk blockIdx.x: one class per wave per pass, the
+// a launch boundary), then its waves walk the classes of chunk blockIdx.x: four classes per wave per pass, a
 // weight row read as two 16-byte loads per lane per 1024 columns.  keys[b] must be 0 on entry (mgx_decode_commit
 // leaves it so).  logits (optional) [B,V] fp32.
 template <int NV>   // d <= 1024 * NV: every thread normalises 4 * NV columns
@@ -103,21 +103,32 @@ __global__ __launch_bounds__(256) void head_argmax_kernel(const bf16_t* __restri
     // classes of this chunk
     const int v0 = blockIdx.x * vper, v1 = min(v0 + vper, V);
     unsigned long long mine = 0;
-    for (int cls = v0 + w; cls < v1; cls += 4) {
-        const bf16_t* wr = W + (long)cls * d;
-        float acc = 0.f;
+    // four classes per pass (their weight rows' loads all in flight before the first FMA: one class at a time was a
+    // chain of ~1 us memory round trips, 28 us for the launch)
+    for (int c0 = v0 + 4 * w; c0 < v1; c0 += 16) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int col = lane * 8; col < d; col += 512) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(wr + col);
+            bf16x8 a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const bf16x8*>(W + (long)min(c0 + u, v1 - 1) * d + col);
             const bf16x8 yy = *reinterpret_cast<const bf16x8*>(y + col);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc = fmaf((float)a[e], (float)yy[e], acc);
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[u] = fmaf((float)a[u][e], (float)yy[e], acc[u]);
         }
-        acc = wave_sum(acc);
-        const float lg = (float)(bf16_t)(acc + bias[cls]);
-        if (lane == 0) {
-            if (logits) logits[(long)b * V + cls] = lg;
-            const unsigned long long k = argmax_key(lg, cls);
-            mine = k > mine ? k : mine;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cls = c0 + u;
+            const float t = wave_sum(acc[u]);
+            if (cls < v1) {
+                const float lg = (float)(bf16_t)(t + bias[cls]);
+                if (lane == 0) {
+                    if (logits) logits[(long)b * V + cls] = lg;
+                    const unsigned long long k = argmax_key(lg, cls);
+                    mine = k > mine ? k : mine;
+                }
+            }
         }
     }
     if (lane == 0) best[w] = mine;
@@ -165,7 +176,7 @@ extern "C" int mgx_decode_head_argmax(const void* h, int B, int R, int d, const 
     MGX_REQUIRE(B > 0 && R > 0 && V > 0, MGX_EINVAL, "mgx_decode_head_argmax: B=%d R=%d V=%d", B, R, V);
     MGX_REQUIRE(d >= 8 && d % 8 == 0 && d <= 2048, MGX_EUNSUPPORTED,
                 "mgx_decode_head_argmax: d=%d (multiple of 8, at most 2048)", d);
-    const int VC = V >= 64 ? 8 : 1;                       // class chunks: B x 8 workgroups
+    const int VC = V >= 256 ? 16 : (V >= 64 ? 4 : 1);     // class chunks: B x VC workgroups
     const int vper = (V + VC - 1) / VC;
     const dim3 grid(VC, B);
     hipStream_t st = (hipStream_t)stream;
