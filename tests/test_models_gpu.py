@@ -443,3 +443,62 @@ def test_bench_data_parallel_path_on_rccl():
     assert lines[0]["n_gpus"] == lines[1]["n_gpus"] == 1
     assert np.isfinite(lines[1]["final_loss"])
     assert abs(lines[0]["final_loss"] - lines[1]["final_loss"]) < 2e-2      # dropout masks are seeded; bf16 step
+
+
+def test_full_size_properties_of_the_bench_configuration():
+    """BASELINE configs[1] at full size (alibi_unified d=1024 L=6 H=8 ff=4096, bf16, batch 16 x seq 2048), where the
+    oracle is too slow: size-independent properties of the same kernels.
+      * determinism: two forward+backward passes give bit-identical logits and gradients (no atomics anywhere);
+      * causality: changing tokens at positions >= p leaves the logits of positions < p bit-identical (p on a
+        32-query wave boundary; inside the straddled wave, equal to bf16 tolerance);
+      * linearity of the backward in the loss scale: a x4 loss gives exactly x4 gradients (power-of-two scale,
+        fp32 gradient accumulation);
+      * padding targets (ignore_index) carry no gradient into the logits."""
+    from musicgeneration_amd.model_baseline import build_everything_unified as cfg
+    args = cfg.m_args.get_copy()
+    args.max_sequence = 2048
+    args.dtype = "bf16"
+    args.dropout = 0.0
+    torch.manual_seed(11)
+    model, crit = cfg.build_model_and_criterion(args)
+    model = model.cuda().train()
+    g = torch.Generator().manual_seed(12)
+    x = torch.randint(2, 618, (16, 2048), generator=g).cuda()
+    y = torch.roll(x, -1, dims=1)
+    y[:, -100:] = 1                                            # pad_index tail
+
+    def run(xx, scale=1.0):
+        model.zero_grad(set_to_none=True)
+        logits = model(xx)
+        loss, _ = crit(logits, y)
+        (loss * scale).backward()
+        return logits.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()}, float(loss.detach())
+
+    l1, g1, loss1 = run(x)
+    l2, g2, loss2 = run(x)
+    assert np.isfinite(loss1) and loss1 == loss2
+    assert torch.equal(l1, l2)
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n
+    # p on a wave's 32-query boundary: the flash kernels' deferred rescale is decided per wave (32 queries), so
+    # queries that share a wave with a changed position may differ in rounding (not in the keys they see)
+    p = 1536
+    x2 = x.clone()
+    x2[:, p:] = torch.randint(2, 618, (16, 2048 - p), generator=g).cuda()
+    l3, _, _ = run(x2)
+    assert torch.equal(l3[:, :p], l1[:, :p])
+    assert not torch.equal(l3[:, p:], l1[:, p:])
+    x3 = x.clone()
+    x3[:, 1500:] = x2[:, 1500:]
+    l5, _, _ = run(x3)
+    assert torch.equal(l5[:, :1472], l1[:, :1472])             # whole waves before the change: bit-identical
+    assert gu.rel_err(l5[:, 1472:1500].float(), l1[:, 1472:1500].float()) < 2e-2
+    _, g4, _ = run(x, scale=4.0)
+    for n in g1:
+        assert torch.equal(g4[n], 4.0 * g1[n]), n
+    # ignore_index rows: d loss / d logits is zero there
+    logits = model(x).detach().requires_grad_(True)
+    loss, _ = crit(logits, y)
+    loss.backward()
+    assert float(logits.grad[:, -100:].abs().max()) == 0.0
+    assert float(logits.grad[:, :-100].abs().max()) > 0.0
