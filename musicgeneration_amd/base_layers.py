@@ -107,6 +107,19 @@ class ShadowCache:
             ent = self._c[(id(p), dtype, "pair")]
         return ent[2] if transposed else ent[1]
 
+    def padded_rows(self, p: torch.Tensor, dtype, rows: int):
+        """Compute-dtype copy of p ([V, ...]) with the leading dimension zero-padded to `rows`, rewritten in place
+        when the master's version changes (the output projection with a padded class dimension)."""
+        key = (id(p), dtype, "pad", rows)
+        ent = self._c.get(key)
+        if ent is None or ent[1].device != p.device:
+            ent = [-1, torch.zeros((rows,) + tuple(p.shape[1:]), dtype=dtype, device=p.device)]
+            self._c[key] = ent
+        if ent[0] != p._version:
+            ent[1][:p.shape[0]].copy_(p.detach())
+            ent[0] = p._version
+        return ent[1]
+
     def clear(self):
         self._c.clear()
 

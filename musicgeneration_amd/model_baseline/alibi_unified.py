@@ -165,6 +165,13 @@ class AlibiTransformer(nn.Module):
         return self.proj_class.weight.to(dt), self.proj_class.bias.to(dt)
 
     def head(self, h, wb=None):
+        if wb is None and ops.padded_head_supported(h, self.proj_class.weight):
+            # class dimension padded to a multiple of 64 inside (the weight gradient then runs on gemm_tn_kernel);
+            # the caller sees the [.., :vocab] view, the criterion goes back to the padded base
+            vp = (self.vocab + 63) // 64 * 64
+            w_pad = self._shadow.padded_rows(self.proj_class.weight, h.dtype, vp)
+            b_pad = self._shadow.padded_rows(self.proj_class.bias, h.dtype, vp)
+            return ops.padded_head(h, self.proj_class.weight, self.proj_class.bias, w_pad, b_pad)[..., :self.vocab]
         w, b = wb if wb is not None else self.head_weights(h.dtype)
         return F.linear(h, w, b)
 
@@ -206,8 +213,18 @@ class Criterion(nn.Module):
         self.ignore_index = pad_index
 
     def forward(self, xs, y):
-        logits = xs if xs.is_contiguous() else xs.contiguous()
-        losses = {"loss": ops.softmax_cross_entropy(logits, y, None, self.ignore_index)}
+        base = xs._base
+        if (base is not None and not xs.is_contiguous() and base.is_contiguous() and xs.storage_offset() == 0
+                and xs.stride(-1) == 1 and xs.dim() >= 2 and xs.stride(-2) == base.shape[-1]
+                and xs.numel() // xs.shape[-1] == base.numel() // base.shape[-1]
+                and all(xs.stride(i) == xs.stride(i + 1) * xs.shape[i + 1] for i in range(xs.dim() - 2))):
+            # the [.., :vocab] view of the model's padded logits: the kernel takes the padded buffer with its row
+            # stride (no contiguous copy, and the gradient arrives padded, as the head's backward wants it)
+            loss = ops.softmax_cross_entropy(base, y, None, self.ignore_index, col0=0, V=xs.shape[-1])
+        else:
+            logits = xs if xs.is_contiguous() else xs.contiguous()
+            loss = ops.softmax_cross_entropy(logits, y, None, self.ignore_index)
+        losses = {"loss": loss}
         return losses["loss"], losses
 
 

@@ -343,6 +343,47 @@ def softmax_cross_entropy(logits, targets, weight=None, ignore_index=None, col0=
 
 
 # ---------------------------------------------------------------------------
+# output projection with a padded class dimension (alibi_unified.py:136-137)
+# ---------------------------------------------------------------------------
+class _PaddedHead(torch.autograd.Function):
+    """logits_pad [T, Vp] = h [T, d] @ w_pad[Vp, d]^T + b_pad, Vp = V rounded up to 64: the vocabularies of this
+    model (618) are not multiples of 8, which keeps the weight gradient [V, d] (K = T = 32,768) off gemm_tn_kernel
+    and leaves the library a 0.18 PF kernel for it.  Padded rows of w_pad are zero, padded columns of the
+    incoming gradient are zero (the CE kernel writes only its V columns of a zeroed buffer)."""
+
+    @staticmethod
+    def forward(ctx, h, w, b, w_pad, b_pad):
+        ctx.save_for_backward(h, w_pad)
+        ctx.V = w.shape[0]
+        return torch.addmm(b_pad, h, w_pad.t())
+
+    @staticmethod
+    def backward(ctx, dp):
+        h, w_pad = ctx.saved_tensors
+        V = ctx.V
+        dp = dp.contiguous()
+        dw = gemm_tn(dp, h)[:V]                              # [Vp, d] fp32 -> rows of the real classes
+        db = colsum(dp)[:V]
+        dh = torch.mm(dp, w_pad)
+        return dh, dw, db, None, None
+
+
+def padded_head_supported(h, w):
+    return (h.dtype == torch.bfloat16 and h.is_cuda and w.dtype == torch.float32 and h.shape[-1] % 8 == 0
+            and PADDED_HEAD)
+
+
+def padded_head(h, w, b, w_pad, b_pad):
+    """h [..., d] bf16, masters w [V, d] / b [V] fp32 (autograd leaves), bf16 shadows w_pad [Vp, d] / b_pad [Vp].
+    Returns the padded logits [..., Vp]; slice [..., :V] for the caller (the criterion finds the base again)."""
+    lead = h.shape[:-1]
+    out = _PaddedHead.apply(h.reshape(-1, h.shape[-1]), w, b, w_pad, b_pad)
+    return out.view(*lead, out.shape[-1])
+
+
+PADDED_HEAD = __import__("os").environ.get("MGX_PADDED_HEAD", "1") != "0"     # A/B switch
+
+# ---------------------------------------------------------------------------
 # final Norm (base_layers.py:36-41) as an autograd op
 # ---------------------------------------------------------------------------
 class _LayerNorm(torch.autograd.Function):
