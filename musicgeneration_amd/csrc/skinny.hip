@@ -4,8 +4,8 @@
 // bias, GELU/ReLU (alibi_unified.py:90), or residual + LayerNorm (alibi_unified.py:88-89,92-94).
 //
 // A library GEMM at M = 192 is a latency chain (~9-15 us for 2-8 MB of weights) followed by separate elementwise
-// launches.  Here the work is cut (N/64) x (M/64) x SPLITS ways into >= ~128 workgroups:
-//   skinny_partial_kernel   grid (N/64, SPLITS, M/64), 4 waves; 64 rows x 64 columns x one K slice (up to 1024
+// launches.  Here the work is cut (N/64) x (M/48 or M/64) x SPLITS ways into >= ~128 workgroups:
+//   skinny_partial_kernel   grid (N/64, SPLITS, row tiles), 4 waves; 48 or 64 rows x 64 columns x one K slice (up to 1024
 //                           deep) per workgroup on v_mfma_f32_16x16x32_bf16.  SPLITS == 1 (the wide projections
 //                           qkv and linear1): bias / activation applied in place, bf16 result, no second launch.
 //                           SPLITS > 1 (the d x d and ff x d projections): fp32 partial tile -> slab [SPLITS][M][N]
