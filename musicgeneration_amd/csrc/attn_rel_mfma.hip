@@ -700,8 +700,10 @@ __device__ __forceinline__ void rel_de_band(
             const char* Gs = Qs + TB;
             const float* Ls = stats + buf * 128;
             const float* Dn = Ls + 64;
+#ifndef REL_ABL_NOSTAGE
             if (t + 1 < ntiles) store_tile(i0 + 64, buf ^ 1);
             if (t + 2 < ntiles) load_tile(i0 + 128);
+#endif
             if (rw0 < S) {                                     // wave-uniform
                 {
                     const int JB = i0 + 32 * tb - rw0;         // key of (query block start, distance rw0)
@@ -728,9 +730,13 @@ __device__ __forceinline__ void rel_de_band(
                             sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], KVL ? lds_read16(Kb + la.row_read(hb, ks)) : kb[ks], sb, 0, 0, 0);
                             if (JB > 0) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], KVL ? lds_read16(Ka + la.row_read(ha, ks)) : ka[ks], sa, 0, 0, 0);
                         }
+#ifdef REL_ABL_NOSKEW
+                        sc = sa + sb;
+#else
                         band_put(skew, sa, 0, l31, h5);
                         band_put(skew, sb, 1, l31, h5);
                         band_get(skew, sc, l31, h5);
+#endif
                     }
                     {
                         f32x16 pa, pb;
@@ -741,9 +747,13 @@ __device__ __forceinline__ void rel_de_band(
                             pb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[ks], KVL ? lds_read16(Kb + TB + la.row_read(hb, ks)) : vb[ks], pb, 0, 0, 0);
                             if (JB > 0) pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[ks], KVL ? lds_read16(Ka + TB + la.row_read(ha, ks)) : va[ks], pa, 0, 0, 0);
                         }
+#ifdef REL_ABL_NOSKEW
+                        dp = pa + pb;
+#else
                         band_put(skew, pa, 0, l31, h5);
                         band_put(skew, pb, 1, l31, h5);
                         band_get(skew, dp, l31, h5);
+#endif
                     }
                     if (!KVL) load_kv(JB + 64);                // this wave's next block (one tile further)
 #pragma unroll
@@ -762,7 +772,11 @@ __device__ __forceinline__ void rel_de_band(
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int il = 8 * (e >> 2) + 4 * h5 + (e & 3);
+#ifdef REL_ABL_NOEXP
+                        float p = sc[e] * c;
+#else
                         float p = fast_exp2(sc[e] * c);
+#endif
                         if (JB + il - l31 < 0) p = 0.f;        // key index below 0 (distance beyond the query)
                         sc[e] = p * dp[e] * scale;
                     }
