@@ -234,8 +234,10 @@ int mgx_gemm_tn_bf16(const void* A, const void* B, void* C, float* workspace, in
  * nn.Linear (base_layers.py:54-57, alibi_unified.py:90,92) together with what follows them in the block:
  *   mode 0: nothing more (c_attn)               mode 1 / 2: GELU (exact erf) / ReLU (linear1, alibi_unified.py:90)
  *   mode 3: LayerNorm(. + res) * gamma + beta   (c_proj + norm1, linear2 + norm2: alibi_unified.py:88-89,92-94)
- * Split over N/64 column tiles x K slices (~one workgroup per CU) with fp32 partial slabs in `workspace`
- * (mgx_skinny_gemm_workspace_floats floats), reduced by a second launch that applies the epilogue.
+ * Split over N/64 column tiles x 48- or 64-row tiles x K slices up to 1024 deep.  Where one slice covers K
+ * (modes 0-2 at K <= 1024) the epilogue runs in the same launch; otherwise fp32 partial slabs go to `workspace`
+ * (mgx_skinny_gemm_workspace_floats floats; always required non-NULL) and a second launch reduces them and
+ * applies the epilogue.
  * N % 64 == 0, K % 64 == 0; mode 3 needs N <= 2048. */
 long mgx_skinny_gemm_workspace_floats(int M, int N, int K);
 int mgx_skinny_gemm_bf16(const void* A, const void* Wt, const float* bias, const void* res, const float* gamma,
