@@ -156,6 +156,8 @@ class AlibiTransformer(nn.Module):
 
     # -- forward ---------------------------------------------------------------
     def embed_tokens(self, x, dtype):
+        if dtype == torch.bfloat16 and ops.embed_bf16_supported(x, self.embed.weight):
+            return ops.embed_bf16(x, self.embed.weight)              # same forward; the table gradient is a GEMM
         return F.embedding(x, self.embed.weight).to(dtype)
 
     def head_weights(self, dt):

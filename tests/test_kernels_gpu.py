@@ -649,3 +649,21 @@ def test_colsum(T, n):
     ref = x.double().sum(0)
     assert float((got.double() - ref).abs().max()) < 1e-4 * max(1.0, T ** 0.5)
     assert torch.equal(got, ops.colsum(x))
+
+
+@pytest.mark.parametrize("V,d,T", [(618, 1024, 4096), (92, 64, 100), (2000, 256, 777)])
+def test_embedding_gemm_backward(V, d, T):
+    """ops.embed_bf16: forward = F.embedding(...).to(bf16) bit for bit; backward (one-hot GEMM on gemm_tn_kernel)
+    against torch's index_add-style embedding backward in fp32 on the same bf16 gradient."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(V + T)
+    table = torch.randn(V, d, generator=g).cuda().requires_grad_(True)
+    tok = torch.randint(0, V, (T,), generator=g).cuda()
+    tok[: T // 3] = 1                                            # a heavily repeated class (padding token)
+    dh = torch.randn(T, d, generator=g).bfloat16().cuda()
+    out = ops.embed_bf16(tok, table)
+    assert torch.equal(out, torch.nn.functional.embedding(tok, table.detach()).bfloat16())
+    out.backward(dh)
+    ref = torch.zeros(V, d, dtype=torch.float64, device="cuda").index_add_(0, tok, dh.double())
+    assert float((table.grad.double() - ref).abs().max()) < 1e-4 * max(1.0, (T / 3) ** 0.5)
+    assert float(table.grad[tok.unique()].abs().sum()) > 0
