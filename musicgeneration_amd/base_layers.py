@@ -107,6 +107,25 @@ class ShadowCache:
             ent = self._c[(id(p), dtype, "pair")]
         return ent[2] if transposed else ent[1]
 
+    def refresh_many(self, params, dtype):
+        """Compute-dtype copies of several (small) masters: every stale one is rewritten in place by ONE
+        multi-tensor copy (a block's four bias vectors were four 5-us cast launches per layer per step)."""
+        stale_dst, stale_src = [], []
+        for p in params:
+            if p.dtype == dtype:
+                continue
+            key = (id(p), dtype)
+            ent = self._c.get(key)
+            if ent is None or ent[1].device != p.device or not isinstance(ent, list):
+                ent = [-1, torch.empty(p.shape, dtype=dtype, device=p.device)]
+                self._c[key] = ent
+            if ent[0] != p._version:
+                stale_dst.append(ent[1])
+                stale_src.append(p.detach())
+                ent[0] = p._version
+        if stale_dst:
+            torch._foreach_copy_(stale_dst, stale_src)
+
     def padded_rows(self, p: torch.Tensor, dtype, rows: int):
         """Compute-dtype copy of p ([V, ...]) with the leading dimension zero-padded to `rows`, rewritten in place
         when the master's version changes (the output projection with a padded class dimension)."""
@@ -144,6 +163,8 @@ class BlockWeights:
         self._pairs = _PAIRS and all(cache.pair_supported(p, dtype, shape) for p, shape in ws)
         if self._pairs:
             cache.refresh_pairs(ws, dtype)               # the block's four weights, both orientations, one launch
+        if self.m_bqkv.is_cuda:
+            cache.refresh_many((self.m_bqkv, self.m_bp, self.m_b1, self.m_b2), dtype)      # and its four biases
 
     def _w(self, name, transposed):
         p, shape = getattr(self, "m_" + name), self._shapes[name]
