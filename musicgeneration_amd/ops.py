@@ -330,7 +330,13 @@ class _SoftmaxXent(torch.autograd.Function):
         T, V, ld, col0, ii = ctx.meta
         g = gloss.reshape(1).to(torch.float32).contiguous()
         # other column ranges of a shared logits buffer belong to other heads: start from zero
-        dlogits = torch.zeros_like(logits) if V != ld else torch.empty_like(logits)
+        if V == ld:
+            dlogits = torch.empty_like(logits)
+        elif col0 == 0 and ld - V < 64:
+            dlogits = torch.empty_like(logits)           # one head with padding columns (ops._PaddedHead): zero only those
+            dlogits.view(-1, ld)[:, V:].zero_()
+        else:
+            dlogits = torch.zeros_like(logits)
         check(lib.mgx_softmax_xent_bwd(_p(logits), _p(tgt), _p(weight), _p(row_lse), _p(sums), _p(g), _p(dlogits), T, V,
                                        ld, col0, ii, _dt(logits), _stream()), "mgx_softmax_xent_bwd")
         return dlogits, None, None, None, None, None
