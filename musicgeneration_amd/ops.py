@@ -274,8 +274,10 @@ def gemm_nt(a, bt, bias=None, res=None, act=None, p_drop=0.0, seed=0, n_pad_to=8
     return c if act is None else (c, c2)
 
 
-def gemm_tn(a, b, out_dtype=torch.float32):
-    """C[M,N] = a[K,M]^T @ b[K,N] (weight gradient), fp32 accumulation over a split K."""
+def gemm_tn(a, b, out_dtype=torch.float32, tag="gemm_tn"):
+    """C[M,N] = a[K,M]^T @ b[K,N] (weight gradient), fp32 accumulation over a split K.
+    tag: name under which bench.py's HIP-event pairs file this launch (the block's four weight gradients are the
+    roofline population; the head and embedding gradients are filed apart)."""
     _need(a, "a", torch.bfloat16)
     _need(b, "b", torch.bfloat16)
     K, M = a.shape
@@ -285,7 +287,7 @@ def gemm_tn(a, b, out_dtype=torch.float32):
     ws_n = lib.mgx_gemm_tn_workspace_floats(M, N, K, None)
     ws = torch.empty(ws_n, dtype=torch.float32, device=a.device)
     c = torch.empty(M, N, dtype=out_dtype, device=a.device)
-    with _timed("gemm_tn", 2.0 * M * N * K):
+    with _timed(tag, 2.0 * M * N * K):
         check(lib.mgx_gemm_tn_bf16(_p(a), _p(b), _p(c), _p(ws), M, N, K, M, N, _dt(c), _stream()), "mgx_gemm_tn_bf16")
     return c
 
@@ -371,7 +373,7 @@ class _EmbedBF16(torch.autograd.Function):
         T = tokens.numel()
         onehot = torch.zeros(T, Vp, dtype=torch.bfloat16, device=dh.device)
         onehot.scatter_(1, tokens.reshape(T, 1).to(torch.int64), 1.0)
-        return None, gemm_tn(onehot, dh.reshape(T, d).contiguous())[:V]
+        return None, gemm_tn(onehot, dh.reshape(T, d).contiguous(), tag="gemm_tn_embed")[:V]
 
 
 def embed_bf16_supported(tokens, table):
@@ -405,7 +407,7 @@ class _PaddedHead(torch.autograd.Function):
         h, w_pad = ctx.saved_tensors
         V = ctx.V
         dp = dp.contiguous()
-        dw = gemm_tn(dp, h)[:V]                              # [Vp, d] fp32 -> rows of the real classes
+        dw = gemm_tn(dp, h, tag="gemm_tn_head")[:V]          # [Vp, d] fp32 -> rows of the real classes
         db = colsum(dp)[:V]
         dh = torch.mm(dp, w_pad)
         return dh, dw, db, None, None
