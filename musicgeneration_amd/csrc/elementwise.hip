@@ -138,29 +138,61 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
         for (int k = 0; k < N; ++k) g_acc[c][k] = b_acc[c][k] = a_acc[c][k] = 0.f;
 
-    for (long row = (long)blockIdx.x * 4 + w; row < T_rows; row += (long)gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
+    // The next row's vectors (raw, 16 bytes each) are requested before the current row's arithmetic and its two
+    // wave reductions: one row at a time left the wave idle for a memory round trip per row (4.2 TB/s).
+    typedef typename Vec<T>::type RawT;
+    float gm[NV][N];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int col = (c * 64 + lane) * N;
+#pragma unroll
+        for (int k = 0; k < N; ++k) gm[c][k] = col < d ? gamma[col + k] : 0.f;
+    }
+    RawT r_dy[NV], r_dy2[NV], r_z[NV];
+    float r_mu = 0.f, r_rs = 0.f;
+    auto request = [&](long row) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const int col = (c * 64 + lane) * N;
+            if (col < d) {
+                r_dy[c] = *reinterpret_cast<const RawT*>(dy + row * d + col);
+                if (dy2) r_dy2[c] = *reinterpret_cast<const RawT*>(dy2 + row * d + col);
+                r_z[c] = *reinterpret_cast<const RawT*>(z + row * d + col);
+            }
+        }
+        r_mu = mean[row];
+        r_rs = rstd[row];
+    };
+    const long stride = (long)gridDim.x * 4;
+    long row = (long)blockIdx.x * 4 + w;
+    if (row < T_rows) request(row);
+    while (row < T_rows) {
+        const float mu = r_mu, rs = r_rs;
         float g[NV][N], xh[NV][N];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
             const int col = (c * 64 + lane) * N;
             if (col < d) {
-                float zz[N];
-                load_vec<T, N>(dy + row * d + col, g[c]);
-                if (dy2) {
-                    float t[N];
-                    load_vec<T, N>(dy2 + row * d + col, t);
-#pragma unroll
-                    for (int k = 0; k < N; ++k) g[c][k] += t[k];
-                }
-                load_vec<T, N>(z + row * d + col, zz);
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
-                    xh[c][k] = (zz[k] - mu) * rs;
+                    g[c][k] = to_f32(r_dy[c][k]);
+                    if (dy2) g[c][k] += to_f32(r_dy2[c][k]);
+                    xh[c][k] = (to_f32(r_z[c][k]) - mu) * rs;
+                }
+            }
+        }
+        const long next = row + stride;
+        if (next < T_rows) request(next);
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const int col = (c * 64 + lane) * N;
+            if (col < d) {
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
                     b_acc[c][k] += g[c][k];
                     g_acc[c][k] = fmaf(g[c][k], xh[c][k], g_acc[c][k]);
-                    g[c][k] *= gamma[col + k];          // dxhat
+                    g[c][k] *= gm[c][k];                // dxhat
                     s1 += g[c][k];
                     s2 = fmaf(g[c][k], xh[c][k], s2);
                 }
@@ -194,6 +226,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 }
             }
         }
+        row = next;
     }
     // block reduction of the 4 waves' column partials, one quantity at a time through [4][d] floats
     const int nq = want_dsum ? 3 : 2;
