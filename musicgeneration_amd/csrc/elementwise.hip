@@ -389,14 +389,30 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
         float acc[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) acc[k] = 0.f;
-        for (long row0 = blockIdx.x; row0 < T_rows; row0 += (long)U * gridDim.x) {
-            float g[U][N], x[U][N];
+        // raw vectors of the next U rows are requested before the arithmetic of the current ones
+        typedef typename Vec<T>::type RawT;
+        RawT rg[U], rx[U];
+        auto request = [&](long row0) {
 #pragma unroll
             for (int q = 0; q < U; ++q) {
                 const long row = min(row0 + (long)q * gridDim.x, T_rows - 1);
-                load_vec<T, N>(dh + row * n + col, g[q]);
-                load_vec<T, N>(pre + row * n + col, x[q]);
+                rg[q] = *reinterpret_cast<const RawT*>(dh + row * n + col);
+                rx[q] = *reinterpret_cast<const RawT*>(pre + row * n + col);
             }
+        };
+        const long step = (long)U * gridDim.x;
+        long row0 = blockIdx.x;
+        if (row0 < T_rows) request(row0);
+        while (row0 < T_rows) {
+            float g[U][N], x[U][N];
+#pragma unroll
+            for (int q = 0; q < U; ++q)
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    g[q][k] = to_f32(rg[q][k]);
+                    x[q][k] = to_f32(rx[q][k]);
+                }
+            if (row0 + step < T_rows) request(row0 + step);
 #pragma unroll
             for (int q = 0; q < U; ++q) {
                 const long row = row0 + (long)q * gridDim.x;
@@ -418,6 +434,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
                     for (int k = 0; k < N; ++k) acc[k] += to_f32(from_f32<T>(g[q][k]));
                 }
             }
+            row0 += step;
         }
 #pragma unroll
         for (int k = 0; k < N; ++k) partial[(size_t)blockIdx.x * n + col + k] = acc[k];
