@@ -330,7 +330,12 @@ def bench_decode(a, device, rank, world):
                 "launches_timed": len(ev), "avg_launch_ms": ms,
                 "bytes_per_launch": by, "timed_in": "launch-by-launch pass of the same continuation",
                 "launch_by_launch_tokens_per_s": B * steps / dt_eager, "graph_tokens_equal": same}
+    # whole-step HBM roofline of SURVEY 8(d): weights read once per step + the K/V rows of every layer at the mean context
+    w_bytes = esz * (sum(p.numel() for l in model.decoder_layers for p in l.parameters()) + model.proj_class.weight.numel())
+    step_bytes = w_bytes + B * 2 * Ln * d * (64 + steps / 2) * esz
+    step_gbs = step_bytes / (dt / steps) / 1e9
     out = {"metric": "decode tokens/sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": 16,
+           "step_bytes": step_bytes, "step_gb_per_s": step_gbs, "step_frac_of_hbm_peak": step_gbs / PEAK_HBM_GBS,
            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": a.dtype, "data": "synthetic primer, random-init weights",
            "config": {"workload": f"decode_unified: alibi_unified d={d} L={Ln}, batch {B}/GPU, {steps}-token greedy "
