@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 
 class GradientBucketer:
-    def __init__(self, model: torch.nn.Module, bucket_mb: float = 32.0, process_group=None):
+    def __init__(self, model: torch.nn.Module, bucket_mb: float = 32.0, process_group=None, tail_mb: float = 4.0):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = process_group
@@ -48,6 +48,18 @@ class GradientBucketer:
             size += nbytes
         if cur:
             self.buckets.append(cur)
+        # The bucket that completes last (the first layers + the embedding) is exchanged with nothing left to
+        # overlap: keep that exposed tail short by splitting its last ~tail_mb of gradients into a bucket of
+        # their own (the rest of it then starts earlier, still under the backward of layer 0).
+        tail_limit = int(tail_mb * 1024 * 1024)
+        last = self.buckets[-1]
+        if len(last) > 1 and sum(p.numel() * p.element_size() for p in last) > 2 * tail_limit:
+            k, size = len(last), 0
+            while k > 1 and size + last[k - 1].numel() * last[k - 1].element_size() <= tail_limit:
+                k -= 1
+                size += last[k].numel() * last[k].element_size()
+            if 0 < k < len(last):
+                self.buckets[-1:] = [last[:k], last[k:]]
         self._flat, self._views = [], []
         if not self.inplace:
             self._alloc_flat()
