@@ -10,6 +10,7 @@ Parameters stay fp32 masters; bf16 shadows are cached per parameter version.
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 from torch import nn
@@ -54,11 +55,23 @@ class ShadowCache:
 
     def __init__(self):
         self._c = {}
+        self._ref = {}
+
+    def _own(self, p):
+        """Entries are keyed by id(p): make sure that id still means this tensor (a parameter that was replaced and
+        freed can hand its id to a new one, whose version counter may well match the stale entry's)."""
+        k = id(p)
+        r = self._ref.get(k)
+        if r is None or r() is not p:
+            for key in [key for key in self._c if key[0] == k]:
+                del self._c[key]
+            self._ref[k] = weakref.ref(p)
 
     def get(self, p: torch.Tensor, dtype, shape=None):
         if dtype == p.dtype:
             t = p.detach()
             return t if shape is None else t.view(shape)
+        self._own(p)
         key = (id(p), dtype)
         ent = self._c.get(key)
         if ent is None or ent[0] != p._version or ent[1].device != p.device:
@@ -68,6 +81,7 @@ class ShadowCache:
 
     def get_t(self, p: torch.Tensor, dtype, shape):
         """Transposed contiguous compute-dtype copy of the 2-D view `shape` of p (cached like get)."""
+        self._own(p)
         key = (id(p), dtype, "t")
         ent = self._c.get(key)
         if ent is None or ent[0] != p._version or ent[1].device != p.device:
@@ -86,6 +100,7 @@ class ShadowCache:
         allocated once), instead of a cast plus a strided transposing copy per weight per optimizer step."""
         stale = []
         for p, shape in items:
+            self._own(p)
             key = (id(p), dtype, "pair")
             ent = self._c.get(key)
             if ent is None or ent[1].device != p.device:
@@ -101,6 +116,7 @@ class ShadowCache:
                 ent[0] = p._version
 
     def pair(self, p: torch.Tensor, dtype, shape, transposed: bool):
+        self._own(p)
         ent = self._c.get((id(p), dtype, "pair"))
         if ent is None or ent[0] != p._version or ent[1].device != p.device:
             self.refresh_pairs([(p, shape)], dtype)
@@ -114,6 +130,7 @@ class ShadowCache:
         for p in params:
             if p.dtype == dtype:
                 continue
+            self._own(p)
             key = (id(p), dtype)
             ent = self._c.get(key)
             if ent is None or ent[1].device != p.device or not isinstance(ent, list):
@@ -129,6 +146,7 @@ class ShadowCache:
     def padded_rows(self, p: torch.Tensor, dtype, rows: int):
         """Compute-dtype copy of p ([V, ...]) with the leading dimension zero-padded to `rows`, rewritten in place
         when the master's version changes (the output projection with a padded class dimension)."""
+        self._own(p)
         key = (id(p), dtype, "pad", rows)
         ent = self._c.get(key)
         if ent is None or ent[1].device != p.device:
@@ -141,6 +159,7 @@ class ShadowCache:
 
     def clear(self):
         self._c.clear()
+        self._ref.clear()
 
 
 class BlockWeights:

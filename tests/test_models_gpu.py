@@ -502,3 +502,17 @@ def test_full_size_properties_of_the_bench_configuration():
     loss.backward()
     assert float(logits.grad[:, -100:].abs().max()) == 0.0
     assert float(logits.grad[:, :-100].abs().max()) > 0.0
+
+
+def test_shadow_cache_follows_replaced_parameters():
+    """The bf16 weight shadows are keyed by id(parameter): a parameter that is replaced (and freed) must not leave
+    its shadow behind for whatever tensor receives the same id next."""
+    from musicgeneration_amd.base_layers import ShadowCache
+    c = ShadowCache()
+    for trial in range(20):
+        p = torch.nn.Parameter(torch.full((64, 64), float(trial)).cuda())
+        s = c.get(p, torch.bfloat16)
+        a = c.pair(p, torch.bfloat16, (64, 64), False)
+        t = c.pair(p, torch.bfloat16, (64, 64), True)
+        assert float(s[0, 0]) == float(trial) and float(a[3, 5]) == float(trial) and float(t[5, 3]) == float(trial)
+        del p, s, a, t                                     # the next Parameter often reuses this id
