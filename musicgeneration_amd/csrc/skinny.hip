@@ -61,32 +61,59 @@ __global__ __launch_bounds__(256) void skinny_partial_kernel(const bf16_t* __res
     const int split = blockIdx.y;
     const int m0 = blockIdx.z * MPAD;
     const int kbeg = split * KC;
-    // weights: row n0 + l15, k = kbeg + 32*ks + 8*g4: everything in flight at once
+    // weights: row n0 + l15, k = kbeg + 32*ks + 8*g4; activations: pieces of 8 rows x 128 B, piece p = (k block,
+    // 8-row group), round-robin over the waves.  Everything is in flight at once; with a deep slice the requests
+    // are issued half by half (k blocks [0, NKB/2) first), so the MFMAs of the first half run while the second
+    // half is still landing.
+    constexpr bool TWO = KS >= 8 && NKB % 2 == 0 && ((NKB / 2) * GROUPS) % 4 == 0;
+    constexpr int HALF_P = (NKB / 2) * GROUPS;            // pieces of the first half
+    // LDS-DMA requests per wave in the second half.  Waiting until only that many requests are outstanding covers
+    // every first-half piece wherever the compiler puts the (register) weight loads: the DMA requests keep their
+    // order among themselves and the second-half pieces are issued last.
+    constexpr int C2 = (NKB * GROUPS - HALF_P) / 4;
     bf16x8 bf[KS];
     const bf16_t* bp = W + (long)(n0 + l15) * K + kbeg + 8 * g4;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) bf[ks] = *reinterpret_cast<const bf16x8*>(bp + 32 * ks);
-    // activations: pieces of 8 rows x 128 B, piece p = (k block, 8-row group), round-robin over the waves
-    for (int p = w; p < NKB * GROUPS; p += 4) {
+    auto stage = [&](int p) {
         const int kb = p / GROUPS, gr = p - kb * GROUPS;
         const int row = 8 * gr + (lane >> 3);
         const int ch = (lane & 7) ^ ((row >> 1) & 7);
         const bf16_t* src = A + (long)min(m0 + row, M - 1) * K + kbeg + 64 * kb + 8 * ch;
         __builtin_amdgcn_global_load_lds((const void*)src, (lds_void*)(smem + (kb * MPAD + 8 * gr) * 128), 16, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    };
     f32x4 acc[NRB];
 #pragma unroll
     for (int i = 0; i < NRB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mfma_steps = [&](int ks0, int ks1) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const char* base = smem + ((ks >> 1) * MPAD) * 128 + sk_img(l15, 4 * (ks & 1) + g4);
+        for (int ks = ks0; ks < ks1; ++ks) {
+            const char* base = smem + ((ks >> 1) * MPAD) * 128 + sk_img(l15, 4 * (ks & 1) + g4);
 #pragma unroll
-        for (int i = 0; i < NRB; ++i) {
-            const bf16x8 af = *reinterpret_cast<const bf16x8*>(base + 2048 * i);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks], af, acc[i], 0, 0, 0);
+            for (int i = 0; i < NRB; ++i) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(base + 2048 * i);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks], af, acc[i], 0, 0, 0);
+            }
         }
+    };
+    if constexpr (TWO) {
+#pragma unroll
+        for (int ks = 0; ks < KS / 2; ++ks) bf[ks] = *reinterpret_cast<const bf16x8*>(bp + 32 * ks);
+        for (int p = w; p < HALF_P; p += 4) stage(p);
+#pragma unroll
+        for (int ks = KS / 2; ks < KS; ++ks) bf[ks] = *reinterpret_cast<const bf16x8*>(bp + 32 * ks);
+        for (int p = HALF_P + w; p < NKB * GROUPS; p += 4) stage(p);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C2) : "memory");
+        __syncthreads();
+        mfma_steps(0, KS / 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        mfma_steps(KS / 2, KS);
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bf[ks] = *reinterpret_cast<const bf16x8*>(bp + 32 * ks);
+        for (int p = w; p < NKB * GROUPS; p += 4) stage(p);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        mfma_steps(0, KS);
     }
     // D[row = n][col = m]: the lane holds C row m0 + 16*i + l15, columns n0 + 4*g4 .. +3.  The tile goes through LDS
     // (rows of 64 + 4 floats: conflict-free both ways) and leaves as whole row segments.
