@@ -31,11 +31,11 @@ class GradientBucketer:
         self.stream = torch.cuda.Stream() if self.cuda else None
         # NCCL/RCCL averages in the collective; gloo has no AVG: pre-divide there
         self.avg = self.cuda and dist.get_backend(process_group) == "nccl"
-        # "inplace" (RCCL only): a bucket is ONE grouped all-reduce over the gradient tensors where they lie
-        # (ncclGroupStart/End through c10d's coalescing manager): no flat copy in either direction.  "flat": the
-        # gradients are packed into a persistent flat buffer first (any backend).
+        # "inplace": a bucket is ONE grouped all-reduce over the gradient tensors where they lie (ncclGroupStart/End
+        # through c10d's coalescing manager; gloo's allreduce_coalesced on the CPU): no flat copy in either
+        # direction.  "flat": the gradients are packed into a persistent flat buffer first.
         mode = os.environ.get("MGX_DP_MODE", "inplace")
-        self.inplace = self.avg and mode == "inplace" and hasattr(dist, "_coalescing_manager")
+        self.inplace = mode == "inplace" and hasattr(dist, "_coalescing_manager")
         limit = int(bucket_mb * 1024 * 1024)
         self.buckets: List[List[torch.nn.Parameter]] = []
         cur, size = [], 0
@@ -107,9 +107,10 @@ class GradientBucketer:
         return dist.all_reduce(flat, group=self.group, async_op=True)
 
     def _exchange_inplace(self, b):
+        op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM          # gloo: sum here, divide after the wait
         with dist._coalescing_manager(group=self.group, async_ops=True) as cm:
             for p in self.buckets[b]:
-                dist.all_reduce(p.grad, op=dist.ReduceOp.AVG, group=self.group)
+                dist.all_reduce(p.grad, op=op, group=self.group)
         return cm
 
     def _launch(self, b):
@@ -144,6 +145,8 @@ class GradientBucketer:
         if self.inplace:
             for b, work in self._work:
                 work.wait()                              # orders the current stream after the collective
+                if not self.avg:
+                    torch._foreach_div_([p.grad for p in self.buckets[b]], self.world)
         else:
             for b, work in self._work:
                 ctx = torch.cuda.stream(self.stream) if self.cuda else _null()

@@ -135,12 +135,16 @@ print("rank", rank, "ok")
 '''
 
 
-def test_gradient_bucketer_gloo_world2(tmp_path):
+@pytest.mark.parametrize("mode", ["inplace", "flat"])
+def test_gradient_bucketer_gloo_world2(tmp_path, mode):
+    """Both exchange modes of the bucketer (grouped in-place all-reduce / packed flat buffers) with two ranks:
+    averaged gradients equal the full-batch gradient of a single process, rank 0's weights are broadcast."""
     script = tmp_path / "dp_worker.py"
-    script.write_text(_DP_WORKER)
-    env = dict(os.environ, MGX_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    script.write_text(_DP_WORKER.replace("ddp = GradientBucketer(", "ddp = GradientBucketer(") +
+                      f"\nassert ddp.inplace == {mode == 'inplace'}\n")
+    env = dict(os.environ, MGX_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MGX_DP_MODE=mode)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", "29517" if mode == "flat" else "29519", str(script)],
                          env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count("ok") == 2
