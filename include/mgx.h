@@ -196,6 +196,10 @@ int mgx_decode_head_argmax(const void* h, int B, int R, int d, const float* gamm
 int mgx_decode_commit(void* seq, int seq_is_int64, long L, int B, int* pos_dev, unsigned long long* keys,
                       void* stream);
 
+/* Token embedding for training: out[T,d] bf16 = table[tokens[t], :] (fp32 [V,d]) rounded to nearest even:
+ * `self.embed(x)` + the autocast cast in one pass (alibi_unified.py:130-131).  tokens int64 [T], clamped to [0, V). */
+int mgx_embed_rows_bf16(const long long* tokens, const float* table, int V, int d, long T, void* out, void* stream);
+
 /* Column sums of a bf16 matrix x [T,n] -> out [n] fp32: the bias gradient of a projection whose output gradient no
  * other kernel of the block reduces (c_attn: dqkv.sum(0), autograd of alibi_unified.py:59 / base_layers.py:54-57).
  * workspace: mgx_colsum_workspace_floats(n) floats.  Fixed summation order (deterministic). */

@@ -49,6 +49,7 @@ PROTOTYPES = {
     "mgx_decode_gather_embed": (_i, [_vp, _i, _l, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mgx_decode_head_argmax": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _vp]),
     "mgx_decode_commit": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp]),
+    "mgx_embed_rows_bf16": (_i, [_vp, _vp, _i, _i, _l, _vp, _vp]),
     "mgx_colsum_workspace_floats": (_l, [_i]),
     "mgx_colsum_bf16": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "mgx_cast_shadow_bf16": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -30,6 +30,24 @@ __global__ __launch_bounds__(256) void gather_embed_kernel(const void* __restric
     }
 }
 
+// training-time embedding rows: out[t, :] = bf16(table[tokens[t], :]) -- F.embedding + .to(bfloat16) in one pass
+// (alibi_unified.py:130-131).  One wave per token row, 16-byte loads, 8-byte stores.
+__global__ __launch_bounds__(256) void embed_rows_kernel(const long* __restrict__ tokens, const float* __restrict__ table,
+                                                          int V, int d, long T, bf16_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    for (long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6); t < T; t += (long)gridDim.x * 4) {
+        long tok = tokens[t];
+        tok = min(max(tok, 0L), (long)V - 1);
+        const float* src = table + tok * d;
+        bf16_t* dst = out + t * d;
+        for (int c = lane * 4; c < d; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+            const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            *reinterpret_cast<bf16x4*>(dst + c) = o;
+        }
+    }
+}
+
 __device__ __forceinline__ unsigned long long argmax_key(float v, int idx) {
     unsigned u = __float_as_uint(v);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // order-preserving map of finite floats to unsigned
@@ -196,5 +214,17 @@ extern "C" int mgx_decode_commit(void* seq, int seq_is_int64, long L, int B, int
     MGX_REQUIRE(B > 0 && L >= 2, MGX_EINVAL, "mgx_decode_commit: B=%d L=%ld", B, L);
     hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, seq, seq_is_int64, L, B, pos_dev, keys);
     MGX_CHECK_LAUNCH("commit");
+    return MGX_OK;
+}
+
+extern "C" int mgx_embed_rows_bf16(const long long* tokens, const float* table, int V, int d, long T, void* out,
+                                   void* stream) {
+    MGX_REQUIRE(tokens && table && out, MGX_EINVAL, "mgx_embed_rows_bf16: null pointer");
+    MGX_REQUIRE(T > 0 && V > 0 && d > 0 && d % 4 == 0, MGX_EUNSUPPORTED, "mgx_embed_rows_bf16: T=%ld V=%d d=%d (d must be a multiple of 4)", T, V, d);
+    long blocks = (T + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const long*)tokens,
+                       table, V, d, T, (bf16_t*)out);
+    MGX_CHECK_LAUNCH("embed_rows");
     return MGX_OK;
 }

@@ -362,7 +362,14 @@ class _EmbedBF16(torch.autograd.Function):
     def forward(ctx, tokens, table):
         ctx.save_for_backward(tokens)
         ctx.V = table.shape[0]
-        return torch.nn.functional.embedding(tokens, table).to(torch.bfloat16)
+        V, d = table.shape
+        tok = tokens.reshape(-1)
+        if tok.dtype != torch.int64:
+            tok = tok.to(torch.int64)
+        tok = tok.contiguous()
+        out = torch.empty(*tokens.shape, d, dtype=torch.bfloat16, device=table.device)
+        check(lib.mgx_embed_rows_bf16(_p(tok), _p(table.detach()), V, d, tok.numel(), _p(out), _stream()), "mgx_embed_rows_bf16")
+        return out
 
     @staticmethod
     def backward(ctx, dh):
@@ -377,7 +384,8 @@ class _EmbedBF16(torch.autograd.Function):
 
 
 def embed_bf16_supported(tokens, table):
-    return (table.is_cuda and table.dtype == torch.float32 and table.shape[1] % 8 == 0 and table.shape[0] <= 4096
+    return (table.is_cuda and tokens.is_cuda and table.is_contiguous() and table.dtype == torch.float32
+            and table.shape[1] % 8 == 0 and table.shape[0] <= 4096
             and torch.is_grad_enabled() and table.requires_grad and EMBED_GEMM_BWD)
 
 
