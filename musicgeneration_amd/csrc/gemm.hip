@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2, const float* bias, const void* res,
+extern "C" int mgx_gemm_nt_r1_bf16(const void* A, const void* Bt, void* C, void* C2, const float* bias, const void* res,
                                 int M, int N, int K, int lda, int ldb, int ldc, int act, float p_drop,
                                 unsigned long long seed, void* stream) {
     MGX_REQUIRE(A && Bt && C, MGX_EINVAL, "mgx_gemm_nt_bf16: null pointer");

@@ -1,0 +1,473 @@
+// bf16 MFMA GEMM, NT form, for the projections of the decoder block (gfx950):
+//   C[M,N] = A[M,K] . Bt[N,K]^T  (+ bias[N]) (+ residual[M,N]) (-> activation / activation backward)
+// Replaces Conv1d.forward (base_layers.py:54-57: reshape -> matmul -> +b), the nn.Linear calls of
+// DecoderBlock.forward (alibi_unified.py:90,92) and the dgrad GEMMs autograd derives from them.
+//
+// Tile 256 x 256 x 64, 8 waves.  A K tile is four 16-KiB "half tiles" (A rows 0-127 / 128-255, Bt rows
+// 0-127 / 128-255), each staged by two LDS-DMA instructions per thread (global_load_lds_dwordx4, no VGPR
+// round trip).  A K tile is computed in four phases, one 128 x 128 quadrant of the block tile per phase:
+// every wave owns a 64 x 32 piece of each quadrant (16 v_mfma_f32_16x16x32_bf16 per phase), so a phase reads
+// ONE A half tile and ONE Bt half tile and a half tile is dead as soon as the phase that moved it to
+// registers is over.  Dead half tiles are restaged at once for the K tile two ahead: 4-5 half tiles
+// (64-80 KiB) are in flight per CU, waited for with counted vmcnt (never 0 inside the loop) and raw
+// s_barrier.  The two waves of every SIMD (waves w and w+4) run one barrier apart: while one issues its 16
+// MFMAs the other issues its fragment reads and its LDS-DMA.  Rules the schedule obeys (program order of a
+// wave: reads, stage, [wait], barrier a, MFMAs, barrier b):
+//   WAR: a half tile is restaged >= 2 phases after the phase that read it;
+//   RAW: a half tile is read >= 1 phase after the phase whose counted wait retired it.
+// The epilogue leaves from the accumulators: v_permlane16_swap pairs make 16 contiguous bytes per lane
+// (64-byte row segments per store instruction), no LDS and no barrier, so a workgroup's stores overlap the
+// main loops of the others.
+#include "mgx_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64, NTHREADS = 512;
+constexpr int HT = 16384;                          // one half tile: 128 rows x 64 k x 2 B
+constexpr int LDS_B = 65536;                       // Bt half tiles start here; slot (X, d) at (2X + d) * HT
+
+struct NtArgs {
+    const char* A;
+    const char* B;
+    bf16_t* C;               // [M,N]
+    bf16_t* C2;              // second output (EPI_ACT) or null
+    const float* bias;       // [N] or null
+    const bf16_t* res;       // [M,N] or null (EPI_PLAIN)
+    const bf16_t* pre;       // [M,N] pre-activation (EPI_DACT)
+    float* colpart;          // [gridM, N] per-row-tile column sums of C (EPI_DACT) or null
+    int M, N, K;
+    int lda, ldb, ldc;
+    float p_drop;
+    unsigned long long seed;
+};
+
+enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DACT = 2 };
+
+// bijective XCD remap: blocks that share an XCD (id % 8) get a contiguous run of tile indices
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7, x = id & 7, k = id >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = x * 0.70710678118654752440f;
+    const float az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);
+    const float erfv = copysignf(fmaf(-poly * t, e, 1.f), z);
+    return 0.5f * x * (1.f + erfv);
+}
+// d/dx gelu(x) = Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    const float z = x * 0.70710678118654752440f;
+    const float az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);      // exp(-x^2/2)
+    const float erfv = copysignf(fmaf(-poly * t, e, 1.f), z);
+    return fmaf(x * 0.3989422804014327f, e, 0.5f * (1.f + erfv));
+}
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    union { bf16x2 v; unsigned u; } x;
+    x.v[0] = (bf16_t)a;
+    x.v[1] = (bf16_t)b;
+    return x.u;
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+#define NT_BAR()                                  \
+    do {                                          \
+        __builtin_amdgcn_sched_barrier(0);        \
+        __builtin_amdgcn_s_barrier();             \
+        __builtin_amdgcn_sched_barrier(0);        \
+    } while (0)
+#define NT_LGKM0()                                             \
+    do {                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);                     \
+    } while (0)
+
+template <int EPI, int ACT, bool DROP, bool STAGGER>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * LDS_B];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int l15 = lane & 15, g4 = lane >> 4;
+
+    // tile order: bands of 8 tile rows, column-major inside a band, so that the ~32 workgroups that share
+    // an XCD at any time cover a compact 8 x 4 rectangle (12 operand panels per K tile for 32 tiles)
+    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, nbm * nbn);
+    const int band = tile / (8 * nbn);
+    const int bh = min(8, nbm - 8 * band);
+    const int rem = tile - band * 8 * nbn;
+    const int bn = rem / bh, bm = 8 * band + (rem - bn * bh);
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    // ---- staging: per-lane source byte offsets (32 bit), [half X][piece i]; piece 2w+i = rows 16w+8i.. of the half tile
+    unsigned sa[2][2], sb[2][2];
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 16 * w + 8 * i + (lane >> 3);
+            const int ch = (lane & 7) ^ ((row >> 1) & 7);
+            sa[X][i] = (unsigned)(((long)min(m0 + 128 * X + row, g.M - 1) * g.lda + ch * 8) * 2);
+            sb[X][i] = (unsigned)(((long)min(n0 + 128 * X + row, g.N - 1) * g.ldb + ch * 8) * 2);
+        }
+    const int nk = g.K / BK;
+    char* const stage_base = smem + 2048 * w;
+    auto stage_a = [&](int X, int d, int kt) {
+        const char* src = g.A + (long)min(kt, nk - 1) * (BK * 2);
+        char* dst = stage_base + (2 * X + d) * HT;
+        __builtin_amdgcn_global_load_lds((const void*)(src + sa[X][0]), (lds_void*)(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(src + sa[X][1]), (lds_void*)(dst + 1024), 16, 0, 0);
+    };
+    auto stage_b = [&](int X, int d, int kt) {
+        const char* src = g.B + (long)min(kt, nk - 1) * (BK * 2);
+        char* dst = stage_base + LDS_B + (2 * X + d) * HT;
+        __builtin_amdgcn_global_load_lds((const void*)(src + sb[X][0]), (lds_void*)(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(src + sb[X][1]), (lds_void*)(dst + 1024), 16, 0, 0);
+    };
+
+    // ---- fragment reads: v_mfma_f32_16x16x32_bf16 operand = row (l & 15) of a 16-row block, 16-byte chunk
+    // 4*ks + (l >> 4) of the 128-byte row; image: chunk index XORed with (row >> 1) & 7 (conflict-free b128 reads)
+    const char* ard[2];
+    const char* brd[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int lo = 1024 * (l15 >> 3) + 128 * (l15 & 7) + 16 * ((4 * ks + g4) ^ ((l15 >> 1) & 7));
+        ard[ks] = smem + lo + 8192 * wr;                 // wave's 64 A rows of the half tile
+        brd[ks] = smem + LDS_B + lo + 4096 * wc;         // wave's 32 Bt rows of the half tile
+    }
+    bf16x8 a[4][2], b0[2][2], b1[2][2];
+    auto read_a = [&](int X, int d) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i][ks] = *reinterpret_cast<const bf16x8*>(ard[ks] + (2 * X + d) * HT + 2048 * i);
+    };
+    auto read_b = [&](bf16x8 (&b)[2][2], int X, int d) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                b[j][ks] = *reinterpret_cast<const bf16x8*>(brd[ks] + (2 * X + d) * HT + 2048 * j);
+    };
+
+    f32x4 acc[2][2][4][2];                               // [qa][qb][16-row block of M][16-row block of N]
+#pragma unroll
+    for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[qa][qb][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // the Bt rows go in as the MFMA "A" operand: D[row = n][col = m], so each lane (one C row m) holds 4
+    // consecutive n per accumulator
+#define NT_MMA(QA, QB, BF)                                                                                         \
+    do {                                                                                                           \
+        __builtin_amdgcn_s_setprio(1);                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                           \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+                    acc[QA][QB][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][ks], a[i][ks], acc[QA][QB][i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                             \
+    } while (0)
+
+    // ---- prologue: K tile 0 whole, A0 / B0 of K tile 1
+    stage_a(0, 0, 0);
+    stage_b(0, 0, 0);
+    stage_b(1, 0, 0);
+    stage_a(1, 0, 0);
+    stage_a(0, 1, 1);
+    stage_b(0, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // A0(0), B0(0), B1(0) landed
+    NT_BAR();
+    if (STAGGER && wr == 1) NT_BAR();
+
+    auto tile_step = [&](auto dtag, int t) {
+        constexpr int d = decltype(dtag)::value;
+        // phase 0: quadrant (A0, B0)
+        read_a(0, d);
+        read_b(b0, 0, d);
+        stage_b(1, d ^ 1, t + 1);
+        NT_BAR();
+        NT_LGKM0();
+        NT_MMA(0, 0, b0);
+        NT_BAR();
+        // phase 1: quadrant (A0, B1)
+        read_b(b1, 1, d);
+        stage_a(1, d ^ 1, t + 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // A1(t) landed (read in phase 2)
+        NT_BAR();
+        NT_LGKM0();
+        NT_MMA(0, 1, b1);
+        NT_BAR();
+        // phase 2: quadrant (A1, B1)
+        read_a(1, d);
+        stage_a(0, d, t + 2);
+        NT_BAR();
+        NT_LGKM0();
+        NT_MMA(1, 1, b1);
+        NT_BAR();
+        // phase 3: quadrant (A1, B0)
+        stage_b(0, d, t + 2);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // A0, B0, B1 of K tile t+1 landed
+        NT_BAR();
+        NT_MMA(1, 0, b0);
+        NT_BAR();
+    };
+    for (int t = 0; t < nk; t += 2) {
+        tile_step(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < nk) tile_step(std::integral_constant<int, 1>{}, t + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the clamped re-loads of the last K tiles
+    if (STAGGER && wr == 0) NT_BAR();
+#undef NT_MMA
+
+    // ---- epilogue from the accumulators -----------------------------------------------------------------
+    // lane (m = l15, g4) holds n = 16 j + 4 g4 + r of the wave's 32 columns; after the 16-lane-row swap of the
+    // packed j = 0 / j = 1 words, even g4 hold n = 4 g4 .. +8 and odd g4 hold n = 16 + 4 (g4 - 1) .. +8
+    const unsigned thr16 = mgx_drop_thr16(g.p_drop);
+    const float keep_scale = mgx_keep_scale(thr16);
+    const int nsw = (g4 & 1) ? 16 + 4 * (g4 - 1) : 4 * g4;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int nb = n0 + 128 * qb + 32 * wc;
+        f32x4 bv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int n = nb + 16 * j + 4 * g4;
+            if (g.bias && n < g.N) bv[j] = *reinterpret_cast<const f32x4*>(g.bias + n);
+        }
+        float csum[2][4];
+        if (EPI == EPI_DACT) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) csum[j][r] = 0.f;
+        }
+#pragma unroll
+        for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + 128 * qa + 64 * wr + 16 * i + l15;
+                const bool row_ok = m < g.M;
+                const int mc = row_ok ? m : g.M - 1;
+                float v[2][4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[j][r] = acc[qa][qb][i][j][r] + bv[j][r];
+                unsigned o[2][2], o2[2][2];
+                if (EPI == EPI_PLAIN && g.res) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int n = nb + 16 * j + 4 * g4;
+                        if (n < g.N) {
+                            const uint2 rr = *reinterpret_cast<const uint2*>(g.res + (long)mc * g.ldc + n);
+                            v[j][0] += bf_lo(rr.x);
+                            v[j][1] += bf_hi(rr.x);
+                            v[j][2] += bf_lo(rr.y);
+                            v[j][3] += bf_hi(rr.y);
+                        }
+                    }
+                }
+                if (EPI == EPI_DACT) {
+                    // v = d(activation output); C = v * mask/(1-p) * act'(pre)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int n = nb + 16 * j + 4 * g4;
+                        uint2 pp = make_uint2(0u, 0u);
+                        if (n < g.N) pp = *reinterpret_cast<const uint2*>(g.pre + (long)mc * g.ldc + n);
+                        const float x[4] = {bf_lo(pp.x), bf_hi(pp.x), bf_lo(pp.y), bf_hi(pp.y)};
+#pragma unroll
+                        for (int r = 0; r < 4; r += 2) {
+                            // the unfused path rounds dh to bf16 before bias_act_bwd reads it
+                            float d0 = (float)(bf16_t)v[j][r], d1 = (float)(bf16_t)v[j][r + 1];
+                            if (DROP) {
+                                bool k0, k1;
+                                mgx_keep_pair(g.seed, (unsigned long long)((long)mc * g.N + n + r), thr16, k0, k1);
+                                d0 = k0 ? d0 * keep_scale : 0.f;
+                                d1 = k1 ? d1 * keep_scale : 0.f;
+                            }
+                            const float g0 = ACT == MGX_ACT_RELU ? (x[r] > 0.f ? 1.f : 0.f) : gelu_grad_fast(x[r]);
+                            const float g1 = ACT == MGX_ACT_RELU ? (x[r + 1] > 0.f ? 1.f : 0.f) : gelu_grad_fast(x[r + 1]);
+                            v[j][r] = d0 * g0;
+                            v[j][r + 1] = d1 * g1;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    o[j][0] = pack2(v[j][0], v[j][1]);
+                    o[j][1] = pack2(v[j][2], v[j][3]);
+                }
+                if (EPI == EPI_DACT) {
+                    // column sums of the ROUNDED values (what a separate pass over C would add up)
+                    if (row_ok) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            csum[j][0] += bf_lo(o[j][0]);
+                            csum[j][1] += bf_hi(o[j][0]);
+                            csum[j][2] += bf_lo(o[j][1]);
+                            csum[j][3] += bf_hi(o[j][1]);
+                        }
+                    }
+                }
+                if (EPI == EPI_ACT) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int n = nb + 16 * j + 4 * g4;
+                        float y[4];
+                        // the activation sees the stored (rounded) pre-activation, as the unfused kernel does
+                        const float x[4] = {bf_lo(o[j][0]), bf_hi(o[j][0]), bf_lo(o[j][1]), bf_hi(o[j][1])};
+#pragma unroll
+                        for (int r = 0; r < 4; r += 2) {
+                            float y0 = ACT == MGX_ACT_RELU ? fmaxf(x[r], 0.f) : gelu_fast(x[r]);
+                            float y1 = ACT == MGX_ACT_RELU ? fmaxf(x[r + 1], 0.f) : gelu_fast(x[r + 1]);
+                            if (DROP) {
+                                bool k0, k1;
+                                mgx_keep_pair(g.seed, (unsigned long long)((long)mc * g.N + n + r), thr16, k0, k1);
+                                y0 = k0 ? y0 * keep_scale : 0.f;
+                                y1 = k1 ? y1 * keep_scale : 0.f;
+                            }
+                            y[r] = y0;
+                            y[r + 1] = y1;
+                        }
+                        o2[j][0] = pack2(y[0], y[1]);
+                        o2[j][1] = pack2(y[2], y[3]);
+                    }
+                }
+                // 16-lane-row swap: odd rows of the j = 0 word <-> even rows of the j = 1 word
+                const int n = nb + nsw;
+                {
+                    auto s0 = __builtin_amdgcn_permlane16_swap(o[0][0], o[1][0], false, false);
+                    auto s1 = __builtin_amdgcn_permlane16_swap(o[0][1], o[1][1], false, false);
+                    if (row_ok && n < g.N)
+                        *reinterpret_cast<uint4*>(g.C + (long)m * g.ldc + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+                if (EPI == EPI_ACT) {
+                    auto s0 = __builtin_amdgcn_permlane16_swap(o2[0][0], o2[1][0], false, false);
+                    auto s1 = __builtin_amdgcn_permlane16_swap(o2[0][1], o2[1][1], false, false);
+                    if (row_ok && n < g.N)
+                        *reinterpret_cast<uint4*>(g.C2 + (long)m * g.ldc + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+            }
+        if (EPI == EPI_DACT && g.colpart) {
+            // wave's partial column sums over its 128 rows of this tile: reduce the 16 lanes of a row group
+            // (xor 1, 2, 4, 8), then lane l15 == 0 of each g4 adds 4 values per j.  Two wave rows (wr) share a
+            // column: fixed slots [bm][wr][N], summed by the host-side reduction in a fixed order.
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s = csum[j][r];
+                    s += __shfl_xor(s, 1, 64);
+                    s += __shfl_xor(s, 2, 64);
+                    s += __shfl_xor(s, 4, 64);
+                    s += __shfl_xor(s, 8, 64);
+                    csum[j][r] = s;
+                }
+            if (l15 == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = nb + 16 * j + 4 * g4;
+                    if (n < g.N)
+                        *reinterpret_cast<f32x4*>(g.colpart + ((long)bm * 2 + wr) * g.N + n) =
+                            f32x4{csum[j][0], csum[j][1], csum[j][2], csum[j][3]};
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+static int nt_check(const char* fn, const void* A, const void* Bt, const void* C, int M, int N, int K, int lda, int ldb,
+                    int ldc) {
+    MGX_REQUIRE(A && Bt && C, MGX_EINVAL, "%s: null pointer", fn);
+    MGX_REQUIRE(M > 0 && N > 0 && K > 0, MGX_EINVAL, "%s: M=%d N=%d K=%d", fn, M, N, K);
+    MGX_REQUIRE(K % BK == 0, MGX_EUNSUPPORTED, "%s: K=%d must be a multiple of %d", fn, K, BK);
+    MGX_REQUIRE(N % 8 == 0, MGX_EUNSUPPORTED, "%s: N=%d must be a multiple of 8 (pad the weight)", fn, N);
+    MGX_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && lda >= K && ldb >= K && ldc >= N, MGX_EUNSUPPORTED,
+                "%s: leading dimensions must be multiples of 8 (16-byte rows): lda=%d ldb=%d ldc=%d", fn, lda, ldb, ldc);
+    MGX_REQUIRE((long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31), MGX_EUNSUPPORTED,
+                "%s: operand larger than 4 GiB (32-bit staging offsets)", fn);
+    const long nblk = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    MGX_REQUIRE(nblk < (1L << 31), MGX_EUNSUPPORTED, "%s: too many tiles", fn);
+    return MGX_OK;
+}
+
+#define NT_LAUNCH(EPI, ACT, DROP)                                                                              \
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, ACT, DROP, true>), dim3((unsigned)nblk), dim3(NTHREADS), 0,        \
+                       (hipStream_t)stream, g)
+
+extern "C" int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2, const float* bias, const void* res,
+                                int M, int N, int K, int lda, int ldb, int ldc, int act, float p_drop,
+                                unsigned long long seed, void* stream) {
+    if (int rc = nt_check("mgx_gemm_nt_bf16", A, Bt, C, M, N, K, lda, ldb, ldc)) return rc;
+    MGX_REQUIRE(act >= -1 && act <= MGX_ACT_RELU, MGX_EINVAL, "mgx_gemm_nt_bf16: bad act %d", act);
+    MGX_REQUIRE(act < 0 || C2, MGX_EINVAL, "mgx_gemm_nt_bf16: activation requested without a second output");
+    MGX_REQUIRE(act < 0 || !res, MGX_EINVAL, "mgx_gemm_nt_bf16: residual and activation epilogues exclude each other");
+    MGX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, MGX_EINVAL, "mgx_gemm_nt_bf16: p_drop=%f", p_drop);
+    NtArgs g{(const char*)A, (const char*)Bt, (bf16_t*)C, (bf16_t*)C2, bias, (const bf16_t*)res, nullptr, nullptr,
+             M, N, K, lda, ldb, ldc, p_drop, seed};
+    const long nblk = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const bool drop = p_drop > 0.f;
+    if (act < 0) NT_LAUNCH(EPI_PLAIN, 0, false);
+    else if (act == MGX_ACT_GELU) { if (drop) NT_LAUNCH(EPI_ACT, MGX_ACT_GELU, true); else NT_LAUNCH(EPI_ACT, MGX_ACT_GELU, false); }
+    else { if (drop) NT_LAUNCH(EPI_ACT, MGX_ACT_RELU, true); else NT_LAUNCH(EPI_ACT, MGX_ACT_RELU, false); }
+    MGX_CHECK_LAUNCH("gemm_nt");
+    return MGX_OK;
+}
+
+extern "C" long mgx_gemm_nt_dact_colpart_floats(int M, int N) { return (long)((M + BM - 1) / BM) * 2 * N; }
+
+extern "C" int mgx_gemm_nt_dact_bf16(const void* A, const void* Bt, const void* pre, void* C, float* colpart, int M, int N,
+                                     int K, int lda, int ldb, int ldc, int act, float p_drop, unsigned long long seed,
+                                     void* stream) {
+    if (int rc = nt_check("mgx_gemm_nt_dact_bf16", A, Bt, C, M, N, K, lda, ldb, ldc)) return rc;
+    MGX_REQUIRE(pre, MGX_EINVAL, "mgx_gemm_nt_dact_bf16: null pre-activation");
+    MGX_REQUIRE(act == MGX_ACT_GELU || act == MGX_ACT_RELU, MGX_EINVAL, "mgx_gemm_nt_dact_bf16: bad act %d", act);
+    MGX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, MGX_EINVAL, "mgx_gemm_nt_dact_bf16: p_drop=%f", p_drop);
+    NtArgs g{(const char*)A, (const char*)Bt, (bf16_t*)C, nullptr, nullptr, nullptr, (const bf16_t*)pre, colpart,
+             M, N, K, lda, ldb, ldc, p_drop, seed};
+    const long nblk = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const bool drop = p_drop > 0.f;
+    if (act == MGX_ACT_GELU) { if (drop) NT_LAUNCH(EPI_DACT, MGX_ACT_GELU, true); else NT_LAUNCH(EPI_DACT, MGX_ACT_GELU, false); }
+    else { if (drop) NT_LAUNCH(EPI_DACT, MGX_ACT_RELU, true); else NT_LAUNCH(EPI_DACT, MGX_ACT_RELU, false); }
+    MGX_CHECK_LAUNCH("gemm_nt_dact");
+    return MGX_OK;
+}
+
+// lab entry (tools/gemm_lab): variant 0 = staggered wave groups, 1 = both groups in lockstep
+extern "C" int mgx_gemm_nt_lab(const void* A, const void* Bt, void* C, const float* bias, int M, int N, int K, int variant,
+                               void* stream) {
+    if (int rc = nt_check("mgx_gemm_nt_lab", A, Bt, C, M, N, K, K, K, N)) return rc;
+    NtArgs g{(const char*)A, (const char*)Bt, (bf16_t*)C, nullptr, bias, nullptr, nullptr, nullptr, M, N, K, K, K, N, 0.f, 0ull};
+    const long nblk = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    if (variant == 0)
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI_PLAIN, 0, false, true>), dim3((unsigned)nblk), dim3(NTHREADS), 0, (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI_PLAIN, 0, false, false>), dim3((unsigned)nblk), dim3(NTHREADS), 0, (hipStream_t)stream, g);
+    MGX_CHECK_LAUNCH("gemm_nt_lab");
+    return MGX_OK;
+}

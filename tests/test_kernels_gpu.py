@@ -184,6 +184,38 @@ def test_relative_attention_bf16_mfma(B, S, H, dh, M, force_generic):
     assert float(dE[:, :M - S].abs().max()) == 0.0 if M > S else True
 
 
+@pytest.mark.parametrize("B,S,H,dh,M", [(1, 2048, 2, 64, 4096), (1, 2304, 1, 64, 4096)])
+def test_relative_attention_bf16_mfma_long(B, S, H, dh, M):
+    """configs[4]'s geometry (max_sequence 4096, dh 64) at S >= 2048: ring skew, band pairing and dE indexing all
+    depend on S and M.  Reference: the closed form of the skew (pinned against the reference's
+    pad/reshape by tests/test_oracle_golden.py::test_relative_tiny) evaluated with torch ops in fp32 on the GPU,
+    on the same bf16-rounded inputs; autograd gives dqkv and dE."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(S + M)
+    qkv = torch.randn(B, S, 3 * H * dh, generator=g).bfloat16().cuda()
+    E = (0.5 * torch.randn(H, M, dh, generator=g)).bfloat16().cuda()
+    dout = torch.randn(B, S, H * dh, generator=g).bfloat16().cuda()
+    ref_in = qkv.float().requires_grad_(True)
+    ref_E = E.float().requires_grad_(True)
+    d = H * dh
+    q, k, v = (t.view(B, S, H, dh).transpose(1, 2) for t in ref_in.split(d, -1))
+    idx = torch.arange(S, device="cuda")
+    dist = (idx.view(S, 1) - idx.view(1, S)).clamp_min(0)                  # i - j for j <= i
+    qe = q @ ref_E[:, M - S:].transpose(-1, -2)                            # [B,H,S,S]: q_i . E[M-S+r]
+    rel = torch.gather(qe, 3, (S - 1 - dist).view(1, 1, S, S).expand(B, H, S, S))   # r = S-1-(i-j)
+    w = (q @ k.transpose(-1, -2) + rel) / math.sqrt(dh)
+    w = w.masked_fill(idx.view(1, S) > idx.view(S, 1), float("-inf"))
+    ref = (w.softmax(-1) @ v).transpose(1, 2).reshape(B, S, d)
+    ref.backward(dout.float())
+    out, lse = ops.rel_attn_fwd(qkv, E, H)
+    dqkv, dE = ops.rel_attn_bwd(dout, qkv, out, lse, E, H)
+    assert gu.rel_err(out.float(), ref) < BF16_TOL
+    assert float((lse - torch.logsumexp(w, -1)).abs().max()) < 2e-2
+    assert gu.rel_err(dqkv.float(), ref_in.grad) < BF16_TOL
+    assert gu.rel_err(dE, ref_E.grad) < BF16_TOL
+    assert float(dE[:, :M - S].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("T,d", [(96, 64), (37, 96), (128, 512), (64, 1024), (20, 2048)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("with_res", [True, False])
@@ -342,7 +374,7 @@ def test_decode_attention(dtype, B, H, dh, R, pos0):
 
 
 @pytest.mark.parametrize("B,H,dh,R,pos0", [(64, 8, 128, 3, 700), (2, 8, 128, 3, 0), (3, 8, 64, 2, 1), (64, 8, 64, 4, 129),
-                                           (1, 8, 128, 3, 2045)])
+                                           (1, 8, 128, 3, 2045), (4, 8, 128, 3, 4158), (2, 8, 64, 3, 4200)])
 def test_decode_attention_streaming_bf16(B, H, dh, R, pos0):
     """The bf16 streaming kernel (both workgroup widths, every R), host- and device-side positions,
     against full causal attention in fp32 on the same bf16-rounded inputs."""

@@ -78,6 +78,114 @@ def test_unified_bf16(name):
         assert m32(x).dtype == torch.bfloat16
 
 
+@pytest.mark.parametrize("dtype,tol", [(None, 1e-5), ("bf16", 2e-2)])
+def test_unified_build_config_full_depth(dtype, tol):
+    """BASELINE configs[1]'s model at full depth and length (d=1024 L=6 H=8 ff=4096, S=2048, B=1) against the
+    reference's own logits (tests/golden/make_golden_r2.py; stored: every 8th position + the last 128) and loss:
+    fp32 within 1e-5, bf16 (MFMA flash attention, every projection on libmgx) within 2e-2."""
+    from musicgeneration_amd.model_baseline.alibi_unified import Criterion
+    z = gu.load("unified_build_l6_s2048")
+    m = _unified_model(z, gu.seeded_state_dict(z), dtype=dtype).eval()
+    x, y = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["y"]).cuda()
+    with torch.no_grad():
+        logits = m(x)
+        loss, _ = Criterion(1).cuda()(logits, y)
+    rows = torch.from_numpy(z["rows"]).cuda()
+    got = logits[0, rows].float().cpu()
+    want = torch.from_numpy(z["logits_rows"])
+    assert float((got - want).abs().max()) < tol * float(z["logits_absmax"])
+    assert abs(float(loss) - float(z["loss"])) < tol * abs(float(z["loss"]))
+
+
+@pytest.mark.parametrize("dtype,tol", [(None, 1e-5), ("bf16", 2e-2)])
+def test_separated_build_width(dtype, tol):
+    """BASELINE configs[2]'s width (embeddings 256/256/512 -> d=1024, 8 heads of 128), one layer, S=256, with the
+    pad (1) and down-weighted (2) classes present: the three logit tensors and the four losses against the
+    reference; bf16 runs the packed 425-column head, the weighted column-slice CE and the dh=128 MFMA attention."""
+    from musicgeneration_amd.model_baseline.alibi_separated import AlibiTransformer, Criterion
+    z = gu.load("separated_dh128_s256")
+    cfg = [int(v) for v in z["cfg"]]
+    m = AlibiTransformer(*cfg, dropout=0.0, dtype=dtype)
+    m.load_state_dict(gu.seeded_state_dict(z))
+    m = m.cuda()
+    crit = Criterion(92, 130, 203, {"loss_notes": 1, "loss_velocity": 0.5, "loss_duration": 2}).cuda()
+    x, y = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["y"]).cuda()
+    preds = m(x)
+    for p, k in zip(preds, ("logit_n", "logit_v", "logit_d")):
+        assert gu.rel_err(p.float(), z[k]) < tol, k
+    loss, ld = crit(preds, y)
+    for k in ("loss", "loss_notes", "loss_velocity", "loss_duration"):
+        assert abs(float(ld[k].detach()) - float(z[k])) < tol * abs(float(z[k])), k
+    loss.backward()
+    named = dict(m.named_parameters())
+    for k, g in gu.grads(z).items():
+        assert named[k].grad.dtype == torch.float32
+        assert gu.rel_err(named[k].grad, g) < (2e-5 if dtype is None else 6e-2), k    # bf16 gradients: informational bound
+
+
+def test_bf16_decode_trunk_matches_flash_forward_and_oracle():
+    """KVCacheDecoder's bf16 trunk (skinny-GEMM projections + the streaming decode-attention kernel: what the decode
+    bench times) at d=1024, three provisional rows against a context of 2100: against the model's own flash forward
+    over the whole sequence and against the CPU oracle in fp32 (2e-2 on the logits, north_star's bf16 bar)."""
+    from musicgeneration_amd.model_baseline.alibi_unified import AlibiTransformer
+    from musicgeneration_amd.decode import KVCacheDecoder
+    torch.manual_seed(7)
+    m = AlibiTransformer(vocab=618, embed_dim=1024, n_layers=2, n_heads=8, max_sequence=2304, proj_forward=4096,
+                         dropout=0.0, dtype="bf16").cuda().eval()
+    B, ctx, R = 2, 2100, 3
+    seq = torch.randint(2, 618, (B, ctx + R), generator=torch.Generator().manual_seed(8)).cuda()
+    dec = KVCacheDecoder(m, B, ctx + R)
+    with torch.no_grad():
+        dec.rows(seq[:, :ctx], 0)
+        part = dec.rows(seq[:, ctx:], ctx).float()
+        full = m(seq)[:, ctx:].float()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    want = O.unified_forward(sd, seq.cpu(), 8)[:, ctx:]
+    assert gu.rel_err(full, want) < 2e-2
+    assert gu.rel_err(part, want) < 2e-2
+    assert gu.rel_err(part, full) < 2e-2
+
+
+def test_full_size_properties_of_the_relative_configuration():
+    """BASELINE configs[4] at full size (RelativeTransformer d=512 L=6 H=8 ff=2048, max_sequence 4096, bf16, batch 2 x
+    seq 4096), where the oracle's [B,H,S,S] tensors are too slow: size-independent properties of the same kernels.
+      * determinism: two forward+backward passes give bit-identical logits and gradients;
+      * causality: changing tokens at positions >= p leaves the logits of positions < p bit-identical (p on a 64-query
+        block boundary);
+      * at S = 2048 < max_sequence the rows of dE the skew never reaches (< max_seq - S) are exactly zero."""
+    from musicgeneration_amd.old_models.relative_transformer import RelativeTransformer
+    torch.manual_seed(21)
+    m = RelativeTransformer(618, 512, 6, 8, 4096, 2048, dropout=0.0, dtype="bf16").cuda().train()
+    g = torch.Generator().manual_seed(22)
+    x = torch.randint(2, 618, (2, 4096), generator=g).cuda()
+    y = torch.roll(x, -1, dims=1)
+
+    def run(xx, yy):
+        m.zero_grad(set_to_none=True)
+        logits = m(xx)
+        loss = torch.nn.functional.cross_entropy(logits.float().reshape(-1, 618), yy.reshape(-1))
+        loss.backward()
+        return logits.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}, float(loss.detach())
+
+    l1, g1, loss1 = run(x, y)
+    l2, g2, loss2 = run(x, y)
+    assert np.isfinite(loss1) and loss1 == loss2
+    assert torch.equal(l1, l2)
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n
+    p = 3072
+    x2 = x.clone()
+    x2[:, p:] = torch.randint(2, 618, (2, 4096 - p), generator=g).cuda()
+    l3, _, _ = run(x2, y)
+    assert torch.equal(l3[:, :p], l1[:, :p])
+    assert not torch.equal(l3[:, p:], l1[:, p:])
+    _, g4, _ = run(x[:, :2048].contiguous(), y[:, :2048].contiguous())
+    for n, gr in g4.items():
+        if n.endswith(".E"):
+            assert float(gr[:, :2048].abs().max()) == 0.0, n
+            assert float(gr[:, 2048:].abs().max()) > 0.0, n
+
+
 def test_state_dict_keys_match_reference():
     z = gu.load("unified_tiny")
     ref_keys = {k[3:] for k in z.files if k.startswith("sd.")}

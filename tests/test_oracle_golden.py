@@ -67,6 +67,35 @@ def test_separated():
         assert gu.rel_err(sd[k].grad, g) < 2e-5, k
 
 
+def test_unified_build_config_full_depth():
+    """The oracle at configs[1]'s full depth and length (tests/golden/make_golden_r2.py)."""
+    z = gu.load("unified_build_l6_s2048")
+    sd = gu.seeded_state_dict(z)
+    x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+    with torch.no_grad():
+        logits = O.unified_forward(sd, x, 8)
+        loss, _ = O.unified_criterion(logits, y, 1)
+    got = logits[0, torch.from_numpy(z["rows"])]
+    assert float((got - torch.from_numpy(z["logits_rows"])).abs().max()) < TOL * float(z["logits_absmax"])
+    assert abs(float(loss) - float(z["loss"])) < TOL * abs(float(z["loss"]))
+
+
+def test_separated_build_width():
+    z = gu.load("separated_dh128_s256")
+    sd = O.make_trainable(gu.seeded_state_dict(z))
+    x, y = torch.from_numpy(z["x"]), torch.from_numpy(z["y"])
+    preds = O.separated_forward(sd, x, 8)
+    for p, k in zip(preds, ("logit_n", "logit_v", "logit_d")):
+        assert gu.rel_err(p, z[k]) < TOL
+    wn, wv = O.separated_class_weights(92, 130)
+    loss, ld = O.separated_criterion(preds, y, wn, wv, {"loss_notes": 1, "loss_velocity": 0.5, "loss_duration": 2})
+    for k in ("loss", "loss_notes", "loss_velocity", "loss_duration"):
+        assert abs(float(ld[k]) - float(z[k])) < TOL * abs(float(z[k])), k
+    loss.backward()
+    for k, g in gu.grads(z).items():
+        assert gu.rel_err(sd[k].grad, g) < 2e-5, k
+
+
 def test_relative_tiny():
     z = gu.load("relative_tiny")
     out = O.skew_relative_logits(torch.from_numpy(z["skew.q"]), torch.from_numpy(z["skew.E"]), 64)
