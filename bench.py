@@ -78,12 +78,8 @@ def build_workload(name, batch, seq, dtype, device):
         from musicgeneration_amd.old_models.relative_transformer import RelativeTransformer
         model = RelativeTransformer(618, 512, 6, 8, max(seq, 4096), 2048, dropout=0.1, dtype=dtype)
 
-        class _CE(torch.nn.Module):
-            def forward(self, logits, y):
-                from musicgeneration_amd import ops
-                l = ops.softmax_cross_entropy(logits.contiguous(), y, None, None)
-                return l, {"loss": l}
-        crit = _CE()
+        from musicgeneration_amd.model_baseline.alibi_unified import Criterion
+        crit = Criterion(None)                                   # plain mean CE (old_models/train.py's loss)
         data = SyntheticUnifiedDataset(batch, seq, seed=1234 + rank, device=device)
         fl = fwd_flops_per_token(6, 512, 2048, seq, 618, 1.5)
         desc = "relative_transformer d=512 L=6 H=8 ff=2048 V=618"
@@ -138,6 +134,9 @@ def main():
     ap.add_argument("--seq", type=int, default=None)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the data-parallel path (RCCL group, gradient bucketer) with one rank: its test on a one-GPU box")
+    ap.add_argument("--dp-mode", default="flat", choices=["flat", "inplace"], help="GradientBucketer exchange mode")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,9 +150,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (musicgeneration_amd has no CPU fallback)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    # MGX_BENCH_FORCE_DP=1: run the data-parallel path (RCCL process group, gradient bucketer, side-stream
-    # all-reduce) even with one rank: the GPU test of that path on a one-GPU box
-    force_dp = world == 1 and os.environ.get("MGX_BENCH_FORCE_DP") == "1"
+    force_dp = world == 1 and a.force_dp
     if force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -175,7 +172,7 @@ def main():
     ddp = None
     if world > 1 or force_dp:
         from musicgeneration_amd.data_parallel import GradientBucketer
-        ddp = GradientBucketer(model)
+        ddp = GradientBucketer(model, mode=a.dp_mode)
     batches = [data.get() for _ in range(4)]          # resident in HBM before the timed region
     model.train()
 

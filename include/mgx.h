@@ -200,6 +200,12 @@ int mgx_decode_commit(void* seq, int seq_is_int64, long L, int B, int* pos_dev, 
  * `self.embed(x)` + the autocast cast in one pass (alibi_unified.py:130-131).  tokens int64 [T], clamped to [0, V). */
 int mgx_embed_rows_bf16(const long long* tokens, const float* table, int V, int d, long T, void* out, void* stream);
 
+/* The same for several token streams at once: tokens [B,n,S] int64 (n <= 4), tables[k] fp32 [V[k], d[k]] (HOST arrays)
+ * -> out [B*S, d[0]+..+d[n-1]] bf16 = concat_k table_k[tokens[b,k,s], :]: the three gathers, the concatenation and the
+ * autocast cast of alibi_separated.py:135-139 in one pass.  d[k] multiples of 4. */
+int mgx_embed_cat_bf16(const long long* tokens, int n, int B, int S, const float* const* tables, const int* V,
+                       const int* d, void* out, void* stream);
+
 /* Column sums of a bf16 matrix x [T,n] -> out [n] fp32: the bias gradient of a projection whose output gradient no
  * other kernel of the block reduces (c_attn: dqkv.sum(0), autograd of alibi_unified.py:59 / base_layers.py:54-57).
  * workspace: mgx_colsum_workspace_floats(n) floats.  Fixed summation order (deterministic). */
@@ -217,14 +223,24 @@ int mgx_cast_shadow_bf16(int count, const float* const* src, void* const* dst, v
 /* ---- bf16 MFMA GEMMs for the projections ----------------------------------------------------
  * Replace Conv1d.forward (base_layers.py:54-57) and nn.Linear (alibi_unified.py:90,92) and their
  * autograd GEMMs.  Tile 256x256x64, fp32 accumulate.
- * NT: C[M,N] = A[M,K] . Bt[N,K]^T (+ bias[N] fp32) (+ res[M,N] bf16); all bf16, K % 64 == 0,
+ * NT: C[M,N] = A[M,K] . Bt[N,K]^T (+ bias[N] fp32) (+ res[M,N] bf16); all bf16, K % 64 == 0, N % 8 == 0,
  *     lda/ldb/ldc multiples of 8.  act = -1: nothing more.  act = MGX_ACT_*: C receives the
  *     pre-activation and C2[M,N] = dropout(act(C)) (dropout keyed by (seed, m*N+n), the same mask
- *     mgx_bias_act_bwd regenerates).
+ *     mgx_bias_act_bwd regenerates); res must be NULL then.
  */
 int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2, const float* bias, const void* res,
                      int M, int N, int K, int lda, int ldb, int ldc, int act, float p_drop,
                      unsigned long long seed, void* stream);
+/* NT with the backward of `drop(activation(.))` (alibi_unified.py:90-91) as its epilogue: the dgrad GEMM of
+ * linear2 (autograd of alibi_unified.py:92) followed by what mgx_bias_act_bwd does, in one launch:
+ *   C[M,N] = (A[M,K] . Bt[N,K]^T) * mask/(1-p) * act'(pre[M,N])      (the GEMM result is rounded to bf16 first,
+ *   as the two-launch path stores it); pre [M,N] bf16 is the saved pre-activation (ld = ldc).
+ *   colpart [mgx_gemm_nt_dact_colpart_floats(M,N)] fp32 (may be NULL) = [2*ceil(M/256), N] partial column sums of
+ *   the rounded C, one row per 128-row slab (plus one for the second wave row of each tile): their sum over rows is
+ *   the bias gradient of linear1; every entry is written (no zero-fill needed), fixed order. */
+long mgx_gemm_nt_dact_colpart_floats(int M, int N);
+int mgx_gemm_nt_dact_bf16(const void* A, const void* Bt, const void* pre, void* C, float* colpart, int M, int N, int K,
+                          int lda, int ldb, int ldc, int act, float p_drop, unsigned long long seed, void* stream);
 /* TN (weight gradients): C[M,N] = A[K,M]^T . B[K,N], bf16 inputs, split over K into fp32 slabs in
  * `workspace` (mgx_gemm_tn_workspace_floats() floats) and reduced in a fixed order (deterministic);
  * C is fp32 or bf16 (out_dtype).  M, N, lda, ldb multiples of 8. */

@@ -50,10 +50,13 @@ PROTOTYPES = {
     "mgx_decode_head_argmax": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _vp]),
     "mgx_decode_commit": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp]),
     "mgx_embed_rows_bf16": (_i, [_vp, _vp, _i, _i, _l, _vp, _vp]),
+    "mgx_embed_cat_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "mgx_colsum_workspace_floats": (_l, [_i]),
     "mgx_colsum_bf16": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "mgx_cast_shadow_bf16": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mgx_gemm_nt_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _vp]),
+    "mgx_gemm_nt_dact_colpart_floats": (_l, [_i, _i]),
+    "mgx_gemm_nt_dact_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _vp]),
     "mgx_gemm_tn_workspace_floats": (_l, [_i, _i, _i, _vp]),
     "mgx_gemm_tn_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mgx_debug_force_generic_attention": (None, [_i]),

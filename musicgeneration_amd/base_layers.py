@@ -9,16 +9,12 @@ Parameters stay fp32 masters; bf16 shadows are cached per parameter version.
 """
 from __future__ import annotations
 
-import os
 import weakref
 
 import torch
 from torch import nn
 
 from . import ops
-
-_PAIRS = os.environ.get("MGX_SHADOW_PAIR", "1") != "0"    # A/B switch: fused two-orientation shadow refresh
-
 
 def generate_square_subsequent_mask(sz, device):
     """0 on/below the diagonal, -inf above (base_layers.py:19-22).  Kept for API
@@ -63,7 +59,7 @@ class ShadowCache:
         k = id(p)
         r = self._ref.get(k)
         if r is None or r() is not p:
-            for key in [key for key in self._c if key[0] == k]:
+            for key in [key for key in self._c if key[0] == k or (isinstance(key[0], tuple) and k in key[0])]:
                 del self._c[key]
             self._ref[k] = weakref.ref(p)
 
@@ -143,19 +139,34 @@ class ShadowCache:
         if stale_dst:
             torch._foreach_copy_(stale_dst, stale_src)
 
-    def padded_rows(self, p: torch.Tensor, dtype, rows: int):
-        """Compute-dtype copy of p ([V, ...]) with the leading dimension zero-padded to `rows`, rewritten in place
-        when the master's version changes (the output projection with a padded class dimension)."""
-        self._own(p)
-        key = (id(p), dtype, "pad", rows)
+    def padded_stack(self, ps, dtype, rows: int, transposed: bool = False):
+        """Compute-dtype copy of the row-wise concatenation of the masters ps ([V_k, ...] each), zero-padded to
+        `rows` rows (the output projections with a padded class dimension); transposed=True gives the [cols, rows]
+        copy (the dX operand).  Allocated once, rewritten in place when any master's version changes."""
+        for p in ps:
+            self._own(p)
+        key = (tuple(id(p) for p in ps), dtype, "pad", rows)
         ent = self._c.get(key)
-        if ent is None or ent[1].device != p.device:
-            ent = [-1, torch.zeros((rows,) + tuple(p.shape[1:]), dtype=dtype, device=p.device)]
+        dev = ps[0].device
+        if ent is None or ent[1].device != dev:
+            pad = torch.zeros((rows,) + tuple(ps[0].shape[1:]), dtype=dtype, device=dev)
+            pad_t = torch.empty((pad.shape[1], rows), dtype=dtype, device=dev) if pad.dim() == 2 else None
+            ent = [None, pad, pad_t, -1]
             self._c[key] = ent
-        if ent[0] != p._version:
-            ent[1][:p.shape[0]].copy_(p.detach())
-            ent[0] = p._version
-        return ent[1]
+        ver = tuple(p._version for p in ps)
+        if ent[0] != ver:
+            r0 = 0
+            for p in ps:
+                ent[1][r0:r0 + p.shape[0]].copy_(p.detach())
+                r0 += p.shape[0]
+            ent[0] = ver
+            ent[3] = -1
+        if not transposed:
+            return ent[1]
+        if ent[3] != 0:                                    # transposed copy follows lazily
+            ent[2].copy_(ent[1].t())
+            ent[3] = 0
+        return ent[2]
 
     def clear(self):
         self._c.clear()
@@ -179,7 +190,7 @@ class BlockWeights:
         self._shapes = {"wqkv": (d, 3 * d), "wp": (d, d), "w1": tuple(self.m_w1.shape), "w2": tuple(self.m_w2.shape)}
         ws = [(self.m_wqkv, self._shapes["wqkv"]), (self.m_wp, self._shapes["wp"]), (self.m_w1, self._shapes["w1"]),
               (self.m_w2, self._shapes["w2"])]
-        self._pairs = _PAIRS and all(cache.pair_supported(p, dtype, shape) for p, shape in ws)
+        self._pairs = all(cache.pair_supported(p, dtype, shape) for p, shape in ws)
         if self._pairs:
             cache.refresh_pairs(ws, dtype)               # the block's four weights, both orientations, one launch
         if self.m_bqkv.is_cuda:
@@ -306,3 +317,29 @@ class Mlp(nn.Module):
 
     def forward(self, x):
         return self.conv_proj(nn.functional.gelu(self.conv_fc(x)))
+
+
+def tied_embed(x, table, dtype):
+    """h = table[x] in the compute dtype for the models whose raw ``embedding`` parameter is both the input table and
+    the output projection (relative_transformer.py:111, old_models/alibi.py, rotary_transformer.py).  bf16: one gather +
+    cast kernel whose backward is a one-hot GEMM."""
+    if dtype == torch.bfloat16 and ops.embed_bf16_supported(x, table):
+        return ops.embed_bf16(x, table)
+    return nn.functional.embedding(x, table if dtype == torch.float32 else table.to(dtype))
+
+
+def tied_head(h, table, shadow: ShadowCache):
+    """logits = h @ table^T, no bias (relative_transformer.py:116-119).  bf16: the class dimension is padded to a
+    multiple of 64 inside and all three GEMMs run on the MFMA kernels; the caller gets the [.., :V] view (the padded
+    buffer rides along as ``mgx_padded_base`` for the criterion)."""
+    V = table.shape[0]
+    if ops.padded_head_supported(h, table):
+        vp = (V + 63) // 64 * 64
+        w_pad = shadow.padded_stack((table,), h.dtype, vp)
+        w_pad_t = shadow.padded_stack((table,), h.dtype, vp, transposed=True)
+        padded = ops.padded_head(h, w_pad, w_pad_t, None, (table, None))
+        logits = padded[..., :V]
+        logits.mgx_padded_base = padded
+        return logits
+    emb = table if h.dtype == torch.float32 else table.to(h.dtype)
+    return (h.reshape(-1, h.shape[-1]) @ emb.t()).reshape(*h.shape[:-1], V)

@@ -48,6 +48,34 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const long* __restrict_
     }
 }
 
+// several token streams x [B, n, S] -> concat_k bf16(table_k[x[b, k, s], :]) as rows of out [B*S, sum d_k]
+// (alibi_separated.py:135-139: three F.embedding gathers + torch.cat + the autocast cast).  One wave per row.
+struct EmbedCat {
+    const float* table[4];
+    int V[4], d[4];
+    int n;
+};
+__global__ __launch_bounds__(256) void embed_cat_kernel(const long* __restrict__ tokens, EmbedCat e, int B, int S, int D,
+                                                         bf16_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long T = (long)B * S;
+    for (long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6); t < T; t += (long)gridDim.x * 4) {
+        const long b = t / S, sidx = t - b * S;
+        bf16_t* dst = out + t * D;
+        for (int k = 0; k < e.n; ++k) {
+            long tok = tokens[(b * e.n + k) * S + sidx];
+            tok = min(max(tok, 0L), (long)e.V[k] - 1);
+            const float* src = e.table[k] + tok * e.d[k];
+            for (int c = lane * 4; c < e.d[k]; c += 256) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+                const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                *reinterpret_cast<bf16x4*>(dst + c) = o;
+            }
+            dst += e.d[k];
+        }
+    }
+}
+
 __device__ __forceinline__ unsigned long long argmax_key(float v, int idx) {
     unsigned u = __float_as_uint(v);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // order-preserving map of finite floats to unsigned
@@ -226,5 +254,29 @@ extern "C" int mgx_embed_rows_bf16(const long long* tokens, const float* table, 
     hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const long*)tokens,
                        table, V, d, T, (bf16_t*)out);
     MGX_CHECK_LAUNCH("embed_rows");
+    return MGX_OK;
+}
+
+extern "C" int mgx_embed_cat_bf16(const long long* tokens, int n, int B, int S, const float* const* tables, const int* V,
+                                  const int* d, void* out, void* stream) {
+    MGX_REQUIRE(tokens && tables && V && d && out, MGX_EINVAL, "mgx_embed_cat_bf16: null pointer");
+    MGX_REQUIRE(n >= 1 && n <= 4 && B > 0 && S > 0, MGX_EINVAL, "mgx_embed_cat_bf16: n=%d B=%d S=%d", n, B, S);
+    EmbedCat e{};
+    e.n = n;
+    int D = 0;
+    for (int k = 0; k < n; ++k) {
+        MGX_REQUIRE(tables[k] && V[k] > 0 && d[k] > 0 && d[k] % 4 == 0, MGX_EUNSUPPORTED,
+                    "mgx_embed_cat_bf16: table %d: V=%d d=%d (d must be a multiple of 4)", k, V[k], d[k]);
+        e.table[k] = tables[k];
+        e.V[k] = V[k];
+        e.d[k] = d[k];
+        D += d[k];
+    }
+    const long T = (long)B * S;
+    long blocks = (T + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(embed_cat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long*>(tokens), e, B, S, D, (bf16_t*)out);
+    MGX_CHECK_LAUNCH("embed_cat");
     return MGX_OK;
 }

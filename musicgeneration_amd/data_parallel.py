@@ -3,26 +3,53 @@ on RCCL (torch.distributed backend "nccl") over xGMI, overlapped with backward.
 
 The reference is single-process; this is new capability.  Design
 for MI355X's point-to-point xGMI (7 links x ~153 GB/s per GPU): parameters are
-packed into ~32 MB buckets in reverse forward order; a bucket's all-reduce is
-issued on a side stream from the autograd hook of its last-arriving gradient,
-so the exchange of layer k hides under the backward GEMMs of layers < k.
-Gradients are averaged (RCCL's AVG; sum / world on gloo) in persistent flat
-buffers whose slots become p.grad afterwards (no scatter copies).  `finish()`
-joins the side stream before the optimizer step.  Works on CPU with gloo for tests (no streams there).
+grouped into ~32 MB buckets in reverse forward order; a bucket's averaged all-reduce
+(RCCL's AVG; sum / world on gloo) is issued from the autograd hook of its last-arriving
+gradient, so the exchange of layer k hides under the backward GEMMs of layers < k, and
+`finish()` joins before the optimizer step.  Two exchange modes, chosen at construction:
+
+  "flat" (default)  the bucket's gradients are packed into a persistent flat buffer (one multi-tensor
+                    copy) that is all-reduced on a side stream; afterwards p.grad IS its slot of that
+                    buffer (no scatter copies).  Public c10d API only.
+  "inplace"         ONE grouped all-reduce over the gradient tensors where they lie (ncclGroupStart/End
+                    through c10d's coalescing manager): no copy in either direction, ~0.4 ms per step
+                    less on the unified model.  It uses a private torch API and has only run with one
+                    RCCL rank and with two gloo ranks in this project, so it is opt-in; a failure raises
+                    (there is no silent change of mode).
+
+Works on CPU with gloo for tests (no streams there).  Multi-GPU RCCL runs are the driver's: on the
+builder's one-GPU boxes the RCCL path has run with a world of one only.
+
+The mean losses of the fused CE kernels normalise by the local sum of target weights (non-pad targets,
+class weights: alibi_unified.py:161, alibi_separated.py:193-195).  Under data parallelism that makes the
+averaged gradient a mean of per-rank means; `GradientBucketer` therefore installs `global_mean_denominator`
+as ops.LOSS_DENOMINATOR_HOOK: every CE then divides by the all-reduced denominator / world, and the average
+over ranks of the per-rank losses (and gradients) equals the single-process loss on the concatenated batch.
 """
 from __future__ import annotations
 
-import os
 from typing import List
 
 import torch
 import torch.distributed as dist
 
 
+def global_mean_denominator(den: torch.Tensor, group=None) -> torch.Tensor:
+    """den: this rank's CE denominators (sum of target weights), any shape, fp32.  Returns sum over ranks / world:
+    mean over ranks of (num_r / returned) == sum_r num_r / sum_r den_r, the loss of the concatenated batch."""
+    world = dist.get_world_size(group)
+    out = den.clone()
+    dist.all_reduce(out, group=group)
+    return out / world
+
+
 class GradientBucketer:
-    def __init__(self, model: torch.nn.Module, bucket_mb: float = 32.0, process_group=None, tail_mb: float = 4.0):
+    def __init__(self, model: torch.nn.Module, bucket_mb: float = 32.0, process_group=None, tail_mb: float = 4.0,
+                 mode: str = "flat", global_loss_normaliser: bool = True):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
+        if mode not in ("flat", "inplace"):
+            raise ValueError(f"mode must be 'flat' or 'inplace', got {mode!r}")
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         params = [p for p in model.parameters() if p.requires_grad]
@@ -31,11 +58,9 @@ class GradientBucketer:
         self.stream = torch.cuda.Stream() if self.cuda else None
         # NCCL/RCCL averages in the collective; gloo has no AVG: pre-divide there
         self.avg = self.cuda and dist.get_backend(process_group) == "nccl"
-        # "inplace": a bucket is ONE grouped all-reduce over the gradient tensors where they lie (ncclGroupStart/End
-        # through c10d's coalescing manager; gloo's allreduce_coalesced on the CPU): no flat copy in either
-        # direction.  "flat": the gradients are packed into a persistent flat buffer first.
-        mode = os.environ.get("MGX_DP_MODE", "inplace")
-        self.inplace = mode == "inplace" and hasattr(dist, "_coalescing_manager")
+        self.inplace = mode == "inplace"
+        if self.inplace and not hasattr(dist, "_coalescing_manager"):
+            raise RuntimeError("mode='inplace' needs torch.distributed._coalescing_manager; use mode='flat'")
         limit = int(bucket_mb * 1024 * 1024)
         self.buckets: List[List[torch.nn.Parameter]] = []
         cur, size = [], 0
@@ -74,6 +99,9 @@ class GradientBucketer:
             torch.autograd.graph.increment_version(p)    # written through .data: version-keyed weight shadows must refresh
         for b in model.buffers():
             dist.broadcast(b.data, src=0, group=process_group)
+        if global_loss_normaliser and self.world > 1:
+            from . import ops
+            ops.LOSS_DENOMINATOR_HOOK = lambda den: global_mean_denominator(den, process_group)
 
     def _alloc_flat(self):
         # one persistent flat buffer per bucket, every parameter's slot 16-byte aligned; after the exchange
@@ -116,15 +144,9 @@ class GradientBucketer:
     def _launch(self, b):
         if self.inplace:
             # c10d orders its RCCL stream after the current stream (the gradients' producer) at the call and the
-            # caller's stream after the collective at wait(): no side stream, no copies
-            try:
-                self._work.append((b, self._exchange_inplace(b)))
-                return
-            except (RuntimeError, ValueError, AttributeError, TypeError):
-                if self._work:
-                    raise                                    # earlier buckets of this step already went in place
-                self.inplace = False                         # this torch build cannot group them: pack instead
-                self._alloc_flat()
+            # caller's stream after the collective at wait(): no side stream, no copies.  Errors propagate.
+            self._work.append((b, self._exchange_inplace(b)))
+            return
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):

@@ -14,8 +14,6 @@ Decode is partitioned by batch only (replicas; no collective).
 """
 from __future__ import annotations
 
-import os
-
 import torch
 
 from . import ops
@@ -76,7 +74,7 @@ class KVCacheDecoder:
                 raise ValueError("prefill (more than 4 rows) must start at position 0")
         T = B * R
         ff = m.decoder_layers[0].linear1.weight.shape[0]
-        skinny = (os.environ.get("MGX_DECODE_GEMM", "mgx") == "mgx" and dt == torch.bfloat16 and T <= 256 and R <= 4
+        skinny = (dt == torch.bfloat16 and T <= 256 and R <= 4
                   and d % 64 == 0 and ff % 64 == 0 and d <= 2048
                   and ops.decode_step_attn_supported(dt, d // m.decoder_layers[0].heads))
         if skinny:
@@ -122,7 +120,7 @@ class KVCacheDecoder:
     def fused_greedy_supported(self, seq: torch.Tensor) -> bool:
         """The three-launch head/tail of a greedy step (csrc/sample.hip): unified model, bf16, d <= 2048."""
         m = self.model
-        return (os.environ.get("MGX_DECODE_TAIL", "mgx") == "mgx" and self.dtype == torch.bfloat16 and seq.dim() == 2
+        return (self.dtype == torch.bfloat16 and seq.dim() == 2
                 and hasattr(m, "embed") and hasattr(m, "proj_class") and m.d_model % 8 == 0 and m.d_model <= 2048
                 and seq.dtype in (torch.int32, torch.int64) and m.embed.weight.dtype == torch.float32)
 
@@ -213,14 +211,12 @@ def _draw(logits_row: torch.Tensor, deterministic: bool) -> torch.Tensor:
 
 @torch.no_grad()
 def sample_next_plus_one(model, seq: torch.Tensor, idx: int = 1, deterministic: bool = False,
-                         progress=None, use_graph=None) -> torch.Tensor:
+                         progress=None, use_graph=True) -> torch.Tensor:
     """KV-cached equivalent of the reference `inference` loops; mutates and returns `seq`.
 
     seq [B,L] (unified) or [B,3,L] (separated), int32 or int64, on the GPU.
-    use_graph: replay the step as a HIP graph (default: env MGX_DECODE_GRAPH, on).
+    use_graph: replay the step as a HIP graph (False: the same kernels, launch by launch).
     """
-    if use_graph is None:
-        use_graph = os.environ.get("MGX_DECODE_GRAPH", "1") != "0"
     separated = seq.dim() == 3
     L = seq.shape[-1]
     B = seq.shape[0]

@@ -61,6 +61,7 @@ class AlibiTransformer(nn.Module):
         self.proj_note = nn.Linear(self.d_model, vocab_note)
         self.proj_velocity = nn.Linear(self.d_model, vocab_velocity)
         self.proj_duration = nn.Linear(self.d_model, vocab_duration)
+        self._shadow = ShadowCache()
         self._register_load_state_dict_pre_hook(_drop_mask_key)
 
     def reference_state_dict(self):
@@ -70,9 +71,10 @@ class AlibiTransformer(nn.Module):
 
     def embed_tokens(self, x, dtype):
         """x [B,3,S] -> [B,S,d_model]: three gathers, concatenated (alibi_separated.py:135-139)."""
-        h = torch.cat([F.embedding(x[:, 0], self.embed_note.weight),
-                       F.embedding(x[:, 1], self.embed_velocity.weight),
-                       F.embedding(x[:, 2], self.embed_duration.weight)], dim=-1)
+        tables = (self.embed_note.weight, self.embed_velocity.weight, self.embed_duration.weight)
+        if dtype == torch.bfloat16 and ops.embed_cat_bf16_supported(x, tables):
+            return ops.embed_cat_bf16(x, tables)             # one launch; the table gradients are one-hot GEMMs
+        h = torch.cat([F.embedding(x[:, k], t) for k, t in enumerate(tables)], dim=-1)
         return h.to(dtype)
 
     def head_weights(self, dt):
@@ -82,9 +84,19 @@ class AlibiTransformer(nn.Module):
         return w, b
 
     def head(self, h, wb=None):
+        sizes = (self.vocab_note, self.vocab_velocity, self.vocab_duration)
+        if wb is None and ops.padded_head_supported(h, self.proj_note.weight):
+            # one [448, d] GEMM for the three heads: stacked, zero-padded shadows kept per parameter version
+            ws = (self.proj_note.weight, self.proj_velocity.weight, self.proj_duration.weight)
+            bs = (self.proj_note.bias, self.proj_velocity.bias, self.proj_duration.bias)
+            vp = (sum(sizes) + 63) // 64 * 64
+            w_pad = self._shadow.padded_stack(ws, h.dtype, vp)
+            w_pad_t = self._shadow.padded_stack(ws, h.dtype, vp, transposed=True)
+            b_pad = self._shadow.padded_stack(bs, torch.float32, vp)
+            packed = ops.padded_head(h, w_pad, w_pad_t, b_pad, (ws[0], bs[0], ws[1], bs[1], ws[2], bs[2]))
+            return SeparatedLogits(packed, sizes)
         w, b = wb if wb is not None else self.head_weights(h.dtype)
-        packed = F.linear(h, w, b)
-        return SeparatedLogits(packed, (self.vocab_note, self.vocab_velocity, self.vocab_duration))
+        return SeparatedLogits(F.linear(h, w, b), sizes)
 
     def forward(self, x: torch.Tensor):
         if x.dim() != 3 or x.shape[1] != 3:
@@ -131,15 +143,16 @@ class Criterion(nn.Module):
         if isinstance(xs, SeparatedLogits):
             packed = xs.packed if xs.packed.is_contiguous() else xs.packed.contiguous()
             n_, v_, d_ = xs.sizes
-            cols = ((packed, 0, n_), (packed, n_, v_), (packed, n_ + v_, d_))
+            # one autograd node for the three heads of the packed buffer: one gradient buffer, filled by column range
+            ln, lv, ld = ops.softmax_cross_entropy_multi(packed, (
+                (y[:, 0], self.weight_n, None, 0, n_), (y[:, 1], self.weight_v, None, n_, v_),
+                (y[:, 2], None, 1, n_ + v_, d_)))
+            losses = {"loss_notes": ln, "loss_velocity": lv, "loss_duration": ld}
         else:
-            cols = tuple((t.contiguous(), 0, t.shape[-1]) for t in xs)
-        losses = {}
-        specs = (("loss_notes", self.weight_n, None), ("loss_velocity", self.weight_v, None),
-                 ("loss_duration", None, 1))
-        for k, (name, w, ii) in enumerate(specs):
-            buf, c0, V = cols[k]
-            losses[name] = ops.softmax_cross_entropy(buf, y[:, k], w, ii, col0=c0, V=V)
+            specs = (("loss_notes", self.weight_n, None), ("loss_velocity", self.weight_v, None),
+                     ("loss_duration", None, 1))
+            losses = {name: ops.softmax_cross_entropy(xs[k].contiguous(), y[:, k], w, ii)
+                      for k, (name, w, ii) in enumerate(specs)}
         loss = sum(self.loss_weights[k] * losses[k] for k in ("loss_notes", "loss_velocity", "loss_duration"))
         losses["loss"] = loss
         return loss, losses

@@ -168,12 +168,17 @@ class AlibiTransformer(nn.Module):
 
     def head(self, h, wb=None):
         if wb is None and ops.padded_head_supported(h, self.proj_class.weight):
-            # class dimension padded to a multiple of 64 inside (the weight gradient then runs on gemm_tn_kernel);
-            # the caller sees the [.., :vocab] view, the criterion goes back to the padded base
+            # class dimension padded to a multiple of 64 inside (all three GEMMs of the head then run on the MFMA
+            # kernels); the caller sees the [.., :vocab] view, the criterion goes back to the padded base
             vp = (self.vocab + 63) // 64 * 64
-            w_pad = self._shadow.padded_rows(self.proj_class.weight, h.dtype, vp)
-            b_pad = self._shadow.padded_rows(self.proj_class.bias, h.dtype, vp)
-            return ops.padded_head(h, self.proj_class.weight, self.proj_class.bias, w_pad, b_pad)[..., :self.vocab]
+            w, b = self.proj_class.weight, self.proj_class.bias
+            w_pad = self._shadow.padded_stack((w,), h.dtype, vp)
+            w_pad_t = self._shadow.padded_stack((w,), h.dtype, vp, transposed=True)
+            b_pad = self._shadow.padded_stack((b,), torch.float32, vp)
+            padded = ops.padded_head(h, w_pad, w_pad_t, b_pad, (w, b))
+            logits = padded[..., :self.vocab]
+            logits.mgx_padded_base = padded          # explicit carrier for Criterion (no copy, padded gradient)
+            return logits
         w, b = wb if wb is not None else self.head_weights(h.dtype)
         return F.linear(h, w, b)
 
@@ -215,12 +220,10 @@ class Criterion(nn.Module):
         self.ignore_index = pad_index
 
     def forward(self, xs, y):
-        base = xs._base
-        if (base is not None and not xs.is_contiguous() and base.is_contiguous() and xs.storage_offset() == 0
-                and xs.stride(-1) == 1 and xs.dim() >= 2 and xs.stride(-2) == base.shape[-1]
-                and xs.numel() // xs.shape[-1] == base.numel() // base.shape[-1]
-                and all(xs.stride(i) == xs.stride(i + 1) * xs.shape[i + 1] for i in range(xs.dim() - 2))):
-            # the [.., :vocab] view of the model's padded logits: the kernel takes the padded buffer with its row
+        base = getattr(xs, "mgx_padded_base", None)
+        if (base is not None and base.is_contiguous() and base.shape[:-1] == xs.shape[:-1]
+                and base.data_ptr() == xs.data_ptr() and xs.stride(-1) == 1 and xs.shape[-1] <= base.shape[-1]):
+            # the model's own [.., :vocab] view of its padded logits: the kernel takes the padded buffer with its row
             # stride (no contiguous copy, and the gradient arrives padded, as the head's backward wants it)
             loss = ops.softmax_cross_entropy(base, y, None, self.ignore_index, col0=0, V=xs.shape[-1])
         else:

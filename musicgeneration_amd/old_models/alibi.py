@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..base_layers import Norm, active_dtype, resolve_dtype
+from ..base_layers import Norm, ShadowCache, active_dtype, resolve_dtype, tied_embed, tied_head
 from ..model_baseline.alibi_unified import DecoderBlock, _activation_name, _drop_mask_key, construct_alibi, get_slopes  # noqa: F401
 
 
@@ -25,6 +25,7 @@ class AlibiTransformer(nn.Module):
         self.decoder_layers = nn.ModuleList(
             [DecoderBlock(n_heads, d_model, proj_forward, act, dropout) for _ in range(n_layers)])
         self.norm = Norm(d_model)
+        self._shadow = ShadowCache()
         self._register_load_state_dict_pre_hook(_drop_mask_key)
 
     def reference_state_dict(self):
@@ -37,13 +38,11 @@ class AlibiTransformer(nn.Module):
         batch, seq_len = x.shape
         dt = active_dtype(self.compute_dtype)
         with torch.autocast("cuda", enabled=False):
-            emb = self.embedding if dt == torch.float32 else self.embedding.to(dt)
-            h = F.embedding(x, emb)
+            h = tied_embed(x, self.embedding, dt)
             for layer in self.decoder_layers:
                 h = layer(h)
             h = self.norm(h)
-            logits = h.reshape(batch * seq_len, self.d_model) @ emb.t()
-            return logits.reshape(batch, seq_len, self.n_vocab)
+            return tied_head(h, self.embedding, self._shadow)
 
 
 def build(args):

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..base_layers import Attention, BlockWeights, Conv1d, Norm, ShadowCache, active_dtype, resolve_dtype, \
+    tied_embed, tied_head, \
     generate_square_subsequent_mask
 from ..model_baseline.alibi_unified import _activation_name
 
@@ -90,6 +91,7 @@ class RelativeTransformer(nn.Module):
         self.decoder_layers = nn.ModuleList(
             [DecoderBlock(n_heads, max_sequence, d_model, proj_forward, act, dropout) for _ in range(n_layers)])
         self.norm = Norm(d_model)
+        self._shadow = ShadowCache()
         self._register_load_state_dict_pre_hook(lambda sd, prefix, *a: sd.pop(prefix + "mask", None))
 
     def reference_state_dict(self):
@@ -105,10 +107,8 @@ class RelativeTransformer(nn.Module):
             raise ValueError(f"sequence length {seq_len} exceeds max_sequence {self.max_sequence}")
         dt = active_dtype(self.compute_dtype)
         with torch.autocast("cuda", enabled=False):
-            emb = self.embedding if dt == torch.float32 else self.embedding.to(dt)
-            h = F.embedding(x, emb)
+            h = tied_embed(x, self.embedding, dt)
             for layer in self.decoder_layers:
                 h = layer(h)
             h = self.norm(h)
-            logits = h.reshape(batch * seq_len, self.d_model) @ emb.t()
-            return logits.reshape(batch, seq_len, self.n_vocab)
+            return tied_head(h, self.embedding, self._shadow)

@@ -10,6 +10,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..base_layers import Attention, BlockWeights, Conv1d, Norm, ShadowCache, active_dtype, resolve_dtype, \
+    tied_embed, tied_head, \
     generate_square_subsequent_mask
 from ..model_baseline.alibi_unified import _activation_name
 
@@ -98,6 +99,7 @@ class RotaryTransformer(nn.Module):
         self.decoder_layers = nn.ModuleList(
             [DecoderBlock(n_heads, d_model, proj_forward, act, dropout) for _ in range(n_layers)])
         self.norm = Norm(d_model)
+        self._shadow = ShadowCache()
         self.pos_embed = FixedPositionalEmbedding(d_model // n_heads, max_sequence)
         self._register_load_state_dict_pre_hook(lambda sd, prefix, *a: sd.pop(prefix + "mask", None))
 
@@ -112,10 +114,8 @@ class RotaryTransformer(nn.Module):
         dt = active_dtype(self.compute_dtype)
         with torch.autocast("cuda", enabled=False):
             pos = self.pos_embed.tables(seq_len, x.device, as_reference=not self.intended_rotation)
-            emb = self.embedding if dt == torch.float32 else self.embedding.to(dt)
-            h = F.embedding(x, emb)
+            h = tied_embed(x, self.embedding, dt)
             for layer in self.decoder_layers:
                 h = layer(h, None, pos)
             h = self.norm(h)
-            logits = h.reshape(batch * seq_len, self.d_model) @ emb.t()
-            return logits.reshape(batch, seq_len, self.n_vocab)
+            return tied_head(h, self.embedding, self._shadow)

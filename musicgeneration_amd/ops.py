@@ -242,13 +242,7 @@ def bias_act_bwd(dh, pre, act="gelu", p_drop=0.0, seed=0):
 # ---------------------------------------------------------------------------
 # bf16 MFMA GEMMs
 # ---------------------------------------------------------------------------
-def gemm_nt_supported(a: torch.Tensor, bt: torch.Tensor) -> bool:
-    """Shapes the hand-written NT kernel takes; anything else is a plain library GEMM (torch.mm)."""
-    return (a.dtype == torch.bfloat16 and bt.dtype == torch.bfloat16 and a.dim() == 2 and bt.dim() == 2
-            and a.shape[1] % 64 == 0 and a.is_contiguous() and bt.is_contiguous())
-
-
-def gemm_nt(a, bt, bias=None, res=None, act=None, p_drop=0.0, seed=0, n_pad_to=8):
+def gemm_nt(a, bt, bias=None, res=None, act=None, p_drop=0.0, seed=0):
     """C = a[M,K] @ bt[N,K]^T (+ bias) (+ res); with act: returns (pre, dropout(act(pre)))."""
     _need(a, "a", torch.bfloat16)
     _need(bt, "bt", torch.bfloat16)
@@ -274,12 +268,34 @@ def gemm_nt(a, bt, bias=None, res=None, act=None, p_drop=0.0, seed=0, n_pad_to=8
     return c if act is None else (c, c2)
 
 
+def gemm_nt_dact(dy, bt, pre, act, p_drop=0.0, seed=0):
+    """Backward through `dropout(act(pre))` fused into the dgrad GEMM that produces its incoming gradient:
+    dpre[M,N] = (dy[M,K] @ bt[N,K]^T) * mask/(1-p) * act'(pre), and dbias[N] = dpre.sum(0) in fp32 (the kernel leaves
+    per-row-tile partial sums, reduced here in a fixed order).  Replaces one GEMM output + one bias_act_bwd pass."""
+    _need(dy, "dy", torch.bfloat16)
+    _need(bt, "bt", torch.bfloat16)
+    _need(pre, "pre", torch.bfloat16)
+    M, K = dy.shape
+    N, K2 = bt.shape
+    if K != K2 or K % 64 or N % 8 or pre.shape != (M, N):
+        raise ValueError(f"gemm_nt_dact: dy {tuple(dy.shape)} bt {tuple(bt.shape)} pre {tuple(pre.shape)}")
+    c = torch.empty(M, N, dtype=torch.bfloat16, device=dy.device)
+    part = torch.empty(int(lib.mgx_gemm_nt_dact_colpart_floats(M, N)), dtype=torch.float32, device=dy.device)
+    with _timed("gemm_nt", 2.0 * M * N * K):
+        check(lib.mgx_gemm_nt_dact_bf16(_p(dy), _p(bt), _p(pre), _p(c), _p(part), M, N, K, K, K, N, _ACT[act],
+                                        float(p_drop), seed, _stream()), "mgx_gemm_nt_dact_bf16")
+    return c, part.view(-1, N).sum(0)
+
+
 def gemm_tn(a, b, out_dtype=torch.float32, tag="gemm_tn"):
-    """C[M,N] = a[K,M]^T @ b[K,N] (weight gradient), fp32 accumulation over a split K.
+    """C[M,N] = a[K,M]^T @ b[K,N] (weight gradient), fp32 accumulation over a split K.  b may be a column slice of a
+    wider row-major matrix (row stride a multiple of 8).
     tag: name under which bench.py's HIP-event pairs file this launch (the block's four weight gradients are the
     roofline population; the head and embedding gradients are filed apart)."""
     _need(a, "a", torch.bfloat16)
-    _need(b, "b", torch.bfloat16)
+    if not b.is_cuda or b.dtype != torch.bfloat16 or b.dim() != 2 or b.stride(1) != 1 or b.stride(0) % 8 or \
+            b.stride(0) < b.shape[1] or b.storage_offset() % 8:
+        raise ValueError("gemm_tn: b must be a bf16 GPU matrix with unit column stride and 16-byte aligned rows")
     K, M = a.shape
     K2, N = b.shape
     if K != K2 or M % 8 or N % 8:
@@ -288,7 +304,8 @@ def gemm_tn(a, b, out_dtype=torch.float32, tag="gemm_tn"):
     ws = torch.empty(ws_n, dtype=torch.float32, device=a.device)
     c = torch.empty(M, N, dtype=out_dtype, device=a.device)
     with _timed(tag, 2.0 * M * N * K):
-        check(lib.mgx_gemm_tn_bf16(_p(a), _p(b), _p(c), _p(ws), M, N, K, M, N, _dt(c), _stream()), "mgx_gemm_tn_bf16")
+        check(lib.mgx_gemm_tn_bf16(_p(a), _p(b), _p(c), _p(ws), M, N, K, M, b.stride(0), _dt(c), _stream()),
+              "mgx_gemm_tn_bf16")
     return c
 
 
@@ -296,6 +313,11 @@ def gemm_tn(a, b, out_dtype=torch.float32, tag="gemm_tn"):
 # softmax cross-entropy
 # ---------------------------------------------------------------------------
 _XENT_SUMS = lib.mgx_xent_sums_len()
+
+# Data parallelism (data_parallel.GradientBucketer installs it): maps this rank's CE denominators (sum of target
+# weights; fp32 tensor) to the value every rank divides by, so that per-rank losses average to the loss of the
+# concatenated batch.  None: single process, the local denominator is the normaliser.
+LOSS_DENOMINATOR_HOOK = None
 
 
 class _SoftmaxXent(torch.autograd.Function):
@@ -322,6 +344,8 @@ class _SoftmaxXent(torch.autograd.Function):
         ii = -100 if ignore_index is None else int(ignore_index)
         check(lib.mgx_softmax_xent_fwd(_p(logits), _p(tgt), _p(weight), _p(row_loss), _p(row_lse), _p(sums), T, V, ld,
                                        col0, ii, _dt(logits), _stream()), "mgx_softmax_xent_fwd")
+        if LOSS_DENOMINATOR_HOOK is not None:
+            sums[1:2].copy_(LOSS_DENOMINATOR_HOOK(sums[1:2]))      # the backward kernel divides by sums[1] too
         ctx.save_for_backward(logits, tgt, weight, row_lse, sums)
         ctx.meta = (T, V, ld, col0, ii)
         return sums[0] / sums[1]
@@ -350,19 +374,102 @@ def softmax_cross_entropy(logits, targets, weight=None, ignore_index=None, col0=
     return _SoftmaxXent.apply(logits, targets, weight, ignore_index, col0, V)
 
 
+class _SoftmaxXentMulti(torch.autograd.Function):
+    """Several heads that share one logits buffer (alibi_separated.py:189-198: notes | velocities | durations in
+    column ranges of the packed projection): one autograd node, ONE gradient buffer that every head's backward
+    kernel fills in its own column range (three zero-filled [T, ld] buffers and their sum otherwise)."""
+
+    @staticmethod
+    def forward(ctx, logits, specs, *tensors):
+        # specs: tuple of (ignore_index, col0, V); tensors: (targets_k, weight_k or None) per head
+        _need(logits, "logits")
+        ld = logits.shape[-1]
+        T = logits.numel() // ld
+        dev = logits.device
+        saved = []
+        for k, (ii, col0, V) in enumerate(specs):
+            tgt, weight = tensors[2 * k], tensors[2 * k + 1]
+            tgt = tgt.reshape(-1)
+            if tgt.dtype != torch.int64:
+                tgt = tgt.to(torch.int64)
+            tgt = tgt.contiguous()
+            if tgt.numel() != T:
+                raise ValueError(f"targets have {tgt.numel()} entries for {T} logit rows")
+            if weight is not None:
+                _need(weight, "weight", torch.float32)
+                if weight.numel() != V:
+                    raise ValueError("class weight size mismatch")
+            row_loss = torch.empty(T, dtype=torch.float32, device=dev)
+            row_lse = torch.empty(T, dtype=torch.float32, device=dev)
+            sums = torch.empty(_XENT_SUMS, dtype=torch.float32, device=dev)
+            iik = -100 if ii is None else int(ii)
+            check(lib.mgx_softmax_xent_fwd(_p(logits), _p(tgt), _p(weight), _p(row_loss), _p(row_lse), _p(sums), T, V, ld,
+                                           col0, iik, _dt(logits), _stream()), "mgx_softmax_xent_fwd")
+            saved += [tgt, weight, row_lse, sums]
+        all_sums = saved[3::4]
+        if LOSS_DENOMINATOR_HOOK is not None:                       # one exchange for every head's denominator
+            den = LOSS_DENOMINATOR_HOOK(torch.stack([t[1] for t in all_sums]))
+            for k, t in enumerate(all_sums):
+                t[1:2].copy_(den[k:k + 1])
+        losses = [t[0] / t[1] for t in all_sums]
+        ctx.save_for_backward(logits, *saved)
+        ctx.specs = specs
+        return tuple(losses)
+
+    @staticmethod
+    def backward(ctx, *glosses):
+        logits, *saved = ctx.saved_tensors
+        ld = logits.shape[-1]
+        T = logits.numel() // ld
+        dlogits = torch.empty_like(logits)
+        flat = dlogits.view(-1, ld)
+        covered = sorted((col0, col0 + V) for _, col0, V in ctx.specs)
+        at = 0
+        for lo, hi in covered + [(ld, ld)]:            # columns no head owns (padding) carry no gradient
+            if lo > at:
+                flat[:, at:lo].zero_()
+            at = max(at, hi)
+        for k, (ii, col0, V) in enumerate(ctx.specs):
+            tgt, weight, row_lse, sums = saved[4 * k:4 * k + 4]
+            g = glosses[k].reshape(1).to(torch.float32).contiguous()
+            iik = -100 if ii is None else int(ii)
+            check(lib.mgx_softmax_xent_bwd(_p(logits), _p(tgt), _p(weight), _p(row_lse), _p(sums), _p(g), _p(dlogits), T, V,
+                                           ld, col0, iik, _dt(logits), _stream()), "mgx_softmax_xent_bwd")
+        return (dlogits, None) + (None,) * (2 * len(ctx.specs))
+
+
+def softmax_cross_entropy_multi(logits, heads):
+    """heads: sequence of (targets, weight | None, ignore_index | None, col0, V).  Returns one fp32 loss per head."""
+    specs = tuple((ii, int(col0), int(V)) for _, _, ii, col0, V in heads)
+    tensors = []
+    for tgt, w, _, _, _ in heads:
+        tensors += [tgt, w]
+    return _SoftmaxXentMulti.apply(logits, specs, *tensors)
+
+
 # ---------------------------------------------------------------------------
 # token embedding with a GEMM backward (alibi_unified.py:130-131)
 # ---------------------------------------------------------------------------
+def _onehot_grad(tokens, dh, V, tag):
+    """dTable [V, d] fp32 = onehot(tokens)^T . dh on gemm_tn_kernel: the one-hot matrix [T, Vp] is bf16 zeros and
+    ones, the products are exact, the sums fp32 in the kernel's fixed order.  dh may be a column slice (row stride >
+    its width) of the gradient of a concatenated embedding."""
+    T = tokens.numel()
+    Vp = (V + 63) // 64 * 64
+    onehot = torch.zeros(T, Vp, dtype=torch.bfloat16, device=dh.device)
+    onehot.scatter_(1, tokens.reshape(T, 1).to(torch.int64), 1.0)
+    return gemm_tn(onehot, dh, tag=tag)[:V]
+
+
 class _EmbedBF16(torch.autograd.Function):
-    """bf16 rows of an fp32 table.  Backward: dTable = onehot(tokens)^T . dh on gemm_tn_kernel (the one-hot matrix
-    [T, Vp] is bf16 zeros and ones, the products are exact, sums are fp32 in the kernel's fixed order) instead of the
-    library's cast + sort + segmented reduction (~0.2 ms per step for a 618-row table)."""
+    """bf16 rows of an fp32 table.  Backward: a one-hot GEMM (_onehot_grad) instead of the library's cast + sort +
+    segmented reduction (~0.2 ms per step for a 618-row table)."""
 
     @staticmethod
     def forward(ctx, tokens, table):
         ctx.save_for_backward(tokens)
-        ctx.V = table.shape[0]
         V, d = table.shape
+        ctx.V = V
         tok = tokens.reshape(-1)
         if tok.dtype != torch.int64:
             tok = tok.to(torch.int64)
@@ -374,67 +481,109 @@ class _EmbedBF16(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh):
         (tokens,) = ctx.saved_tensors
-        V = ctx.V
-        Vp = (V + 63) // 64 * 64
         d = dh.shape[-1]
-        T = tokens.numel()
-        onehot = torch.zeros(T, Vp, dtype=torch.bfloat16, device=dh.device)
-        onehot.scatter_(1, tokens.reshape(T, 1).to(torch.int64), 1.0)
-        return None, gemm_tn(onehot, dh.reshape(T, d).contiguous(), tag="gemm_tn_embed")[:V]
+        return None, _onehot_grad(tokens, dh.reshape(tokens.numel(), d).contiguous(), ctx.V, "gemm_tn_embed")
 
 
 def embed_bf16_supported(tokens, table):
     return (table.is_cuda and tokens.is_cuda and table.is_contiguous() and table.dtype == torch.float32
             and table.shape[1] % 8 == 0 and table.shape[0] <= 4096
-            and torch.is_grad_enabled() and table.requires_grad and EMBED_GEMM_BWD)
+            and torch.is_grad_enabled() and table.requires_grad)
 
 
 def embed_bf16(tokens, table):
     return _EmbedBF16.apply(tokens, table)
 
 
-EMBED_GEMM_BWD = __import__("os").environ.get("MGX_EMBED_GEMM_BWD", "1") != "0"     # A/B switch
+class _EmbedCatBF16(torch.autograd.Function):
+    """Three token streams x [B,3,S] -> concat(embed_k(x[:, k])) [B,S,d_n+d_v+d_d] bf16 in ONE launch
+    (alibi_separated.py:135-139: three gathers, a concatenation and the autocast cast); backward: one one-hot GEMM
+    per table on the matching column slice of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, x, *tables):
+        B, n, S = x.shape
+        tok = x if x.dtype == torch.int64 else x.to(torch.int64)
+        tok = tok.contiguous()
+        widths = [t.shape[1] for t in tables]
+        out = torch.empty(B, S, sum(widths), dtype=torch.bfloat16, device=x.device)
+        import ctypes as C
+        tabs = (C.c_void_p * n)(*[t.detach().data_ptr() for t in tables])
+        vs = (C.c_int * n)(*[t.shape[0] for t in tables])
+        ws = (C.c_int * n)(*widths)
+        check(lib.mgx_embed_cat_bf16(_p(tok), n, B, S, tabs, vs, ws, _p(out), _stream()), "mgx_embed_cat_bf16")
+        ctx.save_for_backward(tok)
+        ctx.meta = ([t.shape[0] for t in tables], widths)
+        return out
+
+    @staticmethod
+    def backward(ctx, dh):
+        (tok,) = ctx.saved_tensors
+        vs, widths = ctx.meta
+        B, n, S = tok.shape
+        dh2 = dh.reshape(B * S, sum(widths))
+        if not dh2.is_contiguous():
+            dh2 = dh2.contiguous()
+        grads, c0 = [], 0
+        for k in range(n):
+            grads.append(_onehot_grad(tok[:, k], dh2[:, c0:c0 + widths[k]], vs[k], "gemm_tn_embed"))
+            c0 += widths[k]
+        return (None, *grads)
+
+
+def embed_cat_bf16_supported(x, tables):
+    return (x.is_cuda and x.dim() == 3 and x.shape[1] == len(tables) <= 4 and torch.is_grad_enabled()
+            and all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.requires_grad
+                    and t.shape[1] % 8 == 0 and t.shape[0] <= 4096 for t in tables))
+
+
+def embed_cat_bf16(x, tables):
+    return _EmbedCatBF16.apply(x, *tables)
+
 
 # ---------------------------------------------------------------------------
 # output projection with a padded class dimension (alibi_unified.py:136-137)
 # ---------------------------------------------------------------------------
 class _PaddedHead(torch.autograd.Function):
-    """logits_pad [T, Vp] = h [T, d] @ w_pad[Vp, d]^T + b_pad, Vp = V rounded up to 64: the vocabularies of this
-    model (618) are not multiples of 8, which keeps the weight gradient [V, d] (K = T = 32,768) off gemm_tn_kernel
-    and leaves the library a 0.18 PF kernel for it.  Padded rows of w_pad are zero, padded columns of the
-    incoming gradient are zero (the CE kernel writes only its V columns of a zeroed buffer)."""
+    """logits_pad [T, Vp] = h [T, d] @ w_pad[Vp, d]^T + b_pad, where w_pad stacks the rows of one or more output
+    projections (alibi_unified.py:136-137: 618 classes; alibi_separated.py:151-154: 92 + 130 + 203) and pads them
+    with zero rows to a multiple of 64: none of these vocabularies is a multiple of 8, which would keep all three
+    GEMMs of the head off the MFMA kernels.  Padded columns of the incoming gradient are zero (the CE kernels write
+    only their own columns)."""
 
     @staticmethod
-    def forward(ctx, h, w, b, w_pad, b_pad):
-        ctx.save_for_backward(h, w_pad)
-        ctx.V = w.shape[0]
-        return torch.addmm(b_pad, h, w_pad.t())
+    def forward(ctx, h, w_pad, w_pad_t, b_pad, sizes, *masters):
+        ctx.save_for_backward(h, w_pad_t)
+        ctx.sizes = sizes
+        return gemm_nt(h, w_pad, b_pad)
 
     @staticmethod
     def backward(ctx, dp):
-        h, w_pad = ctx.saved_tensors
-        V = ctx.V
+        h, w_pad_t = ctx.saved_tensors
         dp = dp.contiguous()
-        dw = gemm_tn(dp, h, tag="gemm_tn_head")[:V]          # [Vp, d] fp32 -> rows of the real classes
-        db = colsum(dp)[:V]
-        dh = torch.mm(dp, w_pad)
-        return dh, dw, db, None, None
+        dw = gemm_tn(dp, h, tag="gemm_tn_head")              # [Vp, d] fp32
+        db = colsum(dp) if ctx.needs_input_grad[6] else None # no bias: the tied heads of old_models/*
+        dh = gemm_nt(dp, w_pad_t)                            # dp [T, Vp] @ w_pad [Vp, d]
+        grads, r0 = [], 0
+        for V in ctx.sizes:                                  # rows of each stacked projection
+            grads += [dw[r0:r0 + V], None if db is None else db[r0:r0 + V]]
+            r0 += V
+        return (dh, None, None, None, None, *grads)
 
 
 def padded_head_supported(h, w):
-    return (h.dtype == torch.bfloat16 and h.is_cuda and w.dtype == torch.float32 and h.shape[-1] % 8 == 0
-            and PADDED_HEAD)
+    return h.dtype == torch.bfloat16 and h.is_cuda and w.dtype == torch.float32 and h.shape[-1] % 64 == 0
 
 
-def padded_head(h, w, b, w_pad, b_pad):
-    """h [..., d] bf16, masters w [V, d] / b [V] fp32 (autograd leaves), bf16 shadows w_pad [Vp, d] / b_pad [Vp].
-    Returns the padded logits [..., Vp]; slice [..., :V] for the caller (the criterion finds the base again)."""
+def padded_head(h, w_pad, w_pad_t, b_pad, masters):
+    """h [..., d] bf16; masters: (weight_0 [V_0, d], bias_0 [V_0], weight_1, bias_1, ...) fp32 autograd leaves;
+    zero-padded stacked shadows w_pad [Vp, d] bf16, w_pad_t [d, Vp] bf16, b_pad [Vp] fp32.  Returns the padded
+    logits [..., Vp]; the caller slices its heads out of it (the criterion goes back to the padded base)."""
     lead = h.shape[:-1]
-    out = _PaddedHead.apply(h.reshape(-1, h.shape[-1]), w, b, w_pad, b_pad)
+    sizes = tuple(int(w.shape[0]) for w in masters[0::2])
+    out = _PaddedHead.apply(h.reshape(-1, h.shape[-1]), w_pad, w_pad_t, b_pad, sizes, *masters)
     return out.view(*lead, out.shape[-1])
 
-
-PADDED_HEAD = __import__("os").environ.get("MGX_PADDED_HEAD", "1") != "0"     # A/B switch
 
 # ---------------------------------------------------------------------------
 # final Norm (base_layers.py:36-41) as an autograd op
@@ -461,40 +610,11 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 # ---------------------------------------------------------------------------
 # whole post-LN decoder block as one autograd node
 # ---------------------------------------------------------------------------
-import os as _os
-
-# bf16 projections.  "mgx": every projection on the hand-written MFMA GEMMs; "torch": every projection a
-# library GEMM (hipBLASLt); "auto" (default): per site, whichever measured faster on MI355X at the
-# training shapes: every weight gradient (TN, split-K, fp32 output) runs on libmgx, the x.W / dy.W^T
-# projections on the library.  The MLP up-projection with its fused bias+GELU+dropout epilogue (gemm_nt_kernel,
-# 412 us) lost the same-box A/B against library GEMM + bias_act_fwd (204 + ~175 us; step 23.88 -> 23.53 ms), so it
-# is no longer an auto site; MGX_AUTO_SITES=mlp1,dwp,dw1,dw2,dwqkv brings it back, MGX_GEMM=mgx runs everything on libmgx.
-GEMM_BACKEND = _os.environ.get("MGX_GEMM", "auto")
-# Operand orientation handed to the library for the projections it runs: "nt" = weight as [N, K] (K contiguous,
-# the transposed shadow where the master is stored [K, N]); "nn" = weight as [K, N]; "native" = whichever
-# orientation the master parameter has.  Measured in the training step on MI355X (hipBLASLt picks a different
-# kernel family per orientation): nt 1.27-1.40 PF vs nn 1.07-1.29 PF at these shapes.
-LIB_LAYOUT = _os.environ.get("MGX_LIB_LAYOUT", "nt")
-
-
-def _pick(native_is_kn, kn, nk):
-    """[K, N]-shaped weight operand for a library GEMM in the configured storage orientation.
-    kn() -> the copy stored [K, N]; nk() -> the copy stored [N, K] (callables: only one is materialised)."""
-    if LIB_LAYOUT == "nt" or (LIB_LAYOUT == "native" and not native_is_kn):
-        return nk().t()
-    return kn()
-
-
-_MLP1_BIAS_IN_GEMM = _os.environ.get("MGX_MLP1_BIAS", "gemm") == "gemm"     # A/B switch
-_AUTO_SITES = frozenset(_os.environ.get("MGX_AUTO_SITES", "dwp,dw1,dw2,dwqkv").split(","))   # A/B switch
-
-
-def _mgx_sites(x2, d, ff):
-    if x2.dtype != torch.bfloat16 or d % 64 or ff % 64 or GEMM_BACKEND == "torch":
-        return frozenset()
-    if GEMM_BACKEND == "mgx":
-        return frozenset({"qkv", "proj", "mlp1", "mlp2", "dw2", "dact", "dw1", "dh1", "dwp", "da", "dwqkv", "dx"})
-    return _AUTO_SITES
+def _mfma_gemms(x2, d, ff):
+    """bf16 blocks whose widths the MFMA GEMMs take (K a multiple of 64 at every projection site) run all twelve
+    GEMMs of the block (four forward, four dgrad, four weight gradients) on libmgx; fp32 (the 1e-5 parity mode) and
+    odd widths use plain library GEMMs."""
+    return x2.dtype == torch.bfloat16 and d % 64 == 0 and ff % 64 == 0
 
 
 class _DecoderBlock(torch.autograd.Function):
@@ -502,7 +622,7 @@ class _DecoderBlock(torch.autograd.Function):
 
     Inputs: x [B,S,d] in the compute dtype, the block's BlockWeights (compute-dtype shadows in
     both orientations) and the fp32 master parameters (autograd leaves).  bf16: projections run on
-    the libmgx MFMA GEMMs (bias / bias+GELU+dropout / residual epilogues, fp32 weight gradients);
+    the libmgx MFMA GEMMs (bias / residual / activation-backward epilogues, fp32 weight gradients);
     fp32 (parity mode) and shapes the kernels do not take use plain library GEMMs.
     """
 
@@ -518,11 +638,11 @@ class _DecoderBlock(torch.autograd.Function):
         p = p_drop if training else 0.0
         seed1 = new_seed() if p > 0 else 0
         seed2 = new_seed() if p > 0 else 0
-        mgx = _mgx_sites(x2, d, ff)
-        if "qkv" in mgx:
+        mfma = _mfma_gemms(x2, d, ff)
+        if mfma:
             qkv = gemm_nt(x2, W.wqkv_t, W.m_bqkv).view(B, S, 3 * d)
         else:
-            qkv = torch.addmm(W.bqkv, x2, _pick(True, lambda: W.wqkv, lambda: W.wqkv_t)).view(B, S, 3 * d)
+            qkv = torch.addmm(W.bqkv, x2, W.wqkv).view(B, S, 3 * d)
         if rope is not None:                      # rotary variant: rotate q | k in place, then plain causal attention
             rope_qk_(qkv, rope[0], rope[1], n_heads)
         if E is None:
@@ -530,49 +650,51 @@ class _DecoderBlock(torch.autograd.Function):
         else:
             a, lse = rel_attn_fwd(qkv, E, n_heads)
         a2 = a.view(T, d)
-        pr = (gemm_nt(a2, W.wp_t, W.m_bp) if "proj" in mgx
-              else torch.addmm(W.bp, a2, _pick(True, lambda: W.wp, lambda: W.wp_t)))
+        pr = gemm_nt(a2, W.wp_t, W.m_bp) if mfma else torch.addmm(W.bp, a2, W.wp)
         h1, z1, mean1, rstd1 = ln_residual_fwd(pr, x2, W.m_g1, W.m_be1, eps, p, seed1)
-        if "mlp1" in mgx:
-            pre, hact = gemm_nt(h1, W.w1, W.m_b1, None, act, p, seed2)
+        if mfma:
+            # bias in the GEMM epilogue, activation + dropout in one HBM-bound pass (the fused bias + GELU +
+            # dropout epilogue costs the GEMM as much VALU time as that pass takes: measured, tools/gemm_lab)
+            pre = gemm_nt(h1, W.w1, W.m_b1)
+            _, hact = bias_act_fwd(pre, None, act, p, seed2)
+            v = gemm_nt(hact, W.w2, W.m_b2)
         else:
-            # bias in the library GEMM's epilogue (bf16 bias, as autocast's F.linear), then activation + dropout
-            # only: two passes over [T, ff] instead of three
-            if _MLP1_BIAS_IN_GEMM:
-                pre = torch.addmm(W.b1, h1, _pick(False, lambda: W.w1_t, lambda: W.w1))
-                _, hact = bias_act_fwd(pre, None, act, p, seed2)
-            else:
-                u = torch.mm(h1, _pick(False, lambda: W.w1_t, lambda: W.w1))
-                pre, hact = bias_act_fwd(u, W.m_b1, act, p, seed2)
-        v = (gemm_nt(hact, W.w2, W.m_b2) if "mlp2" in mgx
-             else torch.addmm(W.b2, hact, _pick(False, lambda: W.w2_t, lambda: W.w2)))
+            u = torch.mm(h1, W.w1_t)
+            pre, hact = bias_act_fwd(u, W.m_b1, act, p, seed2)
+            v = torch.addmm(W.b2, hact, W.w2_t)
         h2, z2, mean2, rstd2 = ln_residual_fwd(v, h1, W.m_g2, W.m_be2, eps)
         ctx.save_for_backward(x2, qkv, a, lse, z1, mean1, rstd1, h1, pre, hact, z2, mean2, rstd2, slopes, E)
         ctx.W = W
-        ctx.cfg = (n_heads, act, p, seed1, seed2, B, S, d, mgx, rope)
+        ctx.cfg = (n_heads, act, p, seed1, seed2, B, S, d, mfma, rope)
         return h2.view(B, S, d)
 
     @staticmethod
     def backward(ctx, dh2):
         x2, qkv, a, lse, z1, mean1, rstd1, h1, pre, hact, z2, mean2, rstd2, slopes, E = ctx.saved_tensors
         W = ctx.W
-        n_heads, act, p, seed1, seed2, B, S, d, mgx, rope = ctx.cfg
+        n_heads, act, p, seed1, seed2, B, S, d, mfma, rope = ctx.cfg
         T = B * S
         f32 = torch.float32
         dh2 = dh2.reshape(T, d).contiguous()
         dz2, _, dg2, dbe2, db2 = ln_residual_bwd(dh2, None, z2, mean2, rstd2, W.m_g2, want_dsum=True)
-        dw2 = gemm_tn(dz2, hact) if "dw2" in mgx else torch.mm(dz2.t(), hact)          # [d, ff]
-        dact = (gemm_nt(dz2, W.w2_t) if "dact" in mgx
-                else torch.mm(dz2, _pick(True, lambda: W.w2, lambda: W.w2_t)))          # [T, ff]
-        dpre, db1 = bias_act_bwd(dact, pre, act, p, seed2)
-        dw1 = gemm_tn(dpre, h1) if "dw1" in mgx else torch.mm(dpre.t(), h1)             # [ff, d]
-        dh1 = (gemm_nt(dpre, W.w1_t) if "dh1" in mgx
-               else torch.mm(dpre, _pick(True, lambda: W.w1, lambda: W.w1_t)))          # [T, d]
+        if mfma:
+            dw2 = gemm_tn(dz2, hact)                                                    # [d, ff]
+            dpre, db1 = gemm_nt_dact(dz2, W.w2_t, pre, act, p, seed2)                   # dz2 @ w2 through act' (+ db1)
+            dw1 = gemm_tn(dpre, h1)                                                     # [ff, d]
+            dh1 = gemm_nt(dpre, W.w1_t)                                                 # [T, d]
+        else:
+            dw2 = torch.mm(dz2.t(), hact)
+            dpre, db1 = bias_act_bwd(torch.mm(dz2, W.w2), pre, act, p, seed2)
+            dw1 = torch.mm(dpre.t(), h1)
+            dh1 = torch.mm(dpre, W.w1)
         dz1, da1, dg1, dbe1, dbp = ln_residual_bwd(dh1, dz2, z1, mean1, rstd1, W.m_g1, p, seed1, want_dsum=True)
         a2 = a.view(T, d)
-        dwp = gemm_tn(a2, da1) if "dwp" in mgx else torch.mm(a2.t(), da1)               # [d, d]
-        da = (gemm_nt(da1, W.wp) if "da" in mgx
-              else torch.mm(da1, _pick(False, lambda: W.wp_t, lambda: W.wp))).view(B, S, d)   # da1 @ wp^T
+        if mfma:
+            dwp = gemm_tn(a2, da1)                                                      # [d, d]
+            da = gemm_nt(da1, W.wp).view(B, S, d)                                       # da1 @ wp^T
+        else:
+            dwp = torch.mm(a2.t(), da1)
+            da = torch.mm(da1, W.wp_t).view(B, S, d)
         if E is None:
             dqkv = alibi_attn_bwd(da, qkv, a, lse, slopes, n_heads)
             dE = None
@@ -582,13 +704,14 @@ class _DecoderBlock(torch.autograd.Function):
             rope_qk_(dqkv, rope[0], rope[1], n_heads, inverse=True)
         dqkv2 = dqkv.view(T, 3 * d)
         dbqkv = colsum(dqkv2) if dqkv2.dtype == torch.bfloat16 and (3 * d) % 8 == 0 else dqkv2.sum(0, dtype=f32)
-        dwqkv = gemm_tn(x2, dqkv2) if "dwqkv" in mgx else torch.mm(x2.t(), dqkv2)       # [d, 3d]
-        if "dx" in mgx:
+        if mfma:
+            dwqkv = gemm_tn(x2, dqkv2)                                                  # [d, 3d]
             dx = gemm_nt(dqkv2, W.wqkv, None, dz1).view(B, S, d)                        # dqkv @ wqkv^T + dz1
         else:
-            # in place: out-of-place addmm first copies dz1 (67 MB) into its result.  dz1 (and da1, which aliases it
+            dwqkv = torch.mm(x2.t(), dqkv2)
+            # in place: out-of-place addmm first copies dz1 into its result.  dz1 (and da1, which aliases it
             # without dropout) has no reader after this point
-            dx = dz1.addmm_(dqkv2, _pick(False, lambda: W.wqkv_t, lambda: W.wqkv)).view(B, S, d)
+            dx = dz1.addmm_(dqkv2, W.wqkv_t).view(B, S, d)
         return (dx, None, None, dE, None, None,
                 dwqkv.unsqueeze(0), dbqkv, dwp.unsqueeze(0), dbp, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2)
 

@@ -8,7 +8,12 @@ step does not stall the GPU:
     (train_utils.py:204-214, including the ``optmizer`` typo);
   * the NaN check (train_utils.py:168) and the logging argmax (:181-182) no longer
     force a device->host sync every step: losses stay on the device and are read
-    back every ``sync_every`` steps;
+    back every ``sync_every`` steps, and ALWAYS before a checkpoint is written, so a
+    ``<step>.tar`` never holds weights that a NaN step has touched (the reference
+    asserts before its optimizer step; here up to ``sync_every`` - 1 updates may
+    follow a NaN loss in memory, but the assertion fires before anything is saved);
+  * eval predictions are queued on the device like the training ones;
+  * under data parallelism only rank 0 writes and prunes checkpoints;
   * the per-step checkpoint-directory glob (:176) runs only after a save;
   * the per-step eval forward (:184-193) is kept but optional via ``eval_every``;
   * ray / wandb are optional: ``Logger`` is an in-process object whose
@@ -174,16 +179,25 @@ def training_loop(model, train_set, criterion, optimizer, lr_scheduler, logger, 
     steps_since_log = 0
     steps_since_checkpoint = 0
     to_dev = lambda t: (torch.from_numpy(t) if not torch.is_tensor(t) else t).to(dev, non_blocking=True)
-    pending = []                            # (pred_argmax, y, loss_dict) kept on the device until the next sync
+    pending = []                            # (logger, pred_argmax, y, loss_dict) kept on the device until the next sync
     it = 0
+    import torch.distributed as dist
+    writer = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
 
     def flush():
-        for pa, yy, ld in pending:
+        for lg, pa, yy, ld in pending:
             vals = {k: float(v) for k, v in ld.items()}
             if any(v != v for v in vals.values()):
+                pending.clear()
                 raise AssertionError("NaN loss")        # train_utils.py:168, checked at the sync point
-            logger.step.remote(recursive_cast(pa, lambda t: t.cpu()), yy.cpu(), vals)
+            lg.step.remote(recursive_cast(pa, lambda t: t.cpu()), yy.cpu(), vals)
         pending.clear()
+
+    def checkpoint():
+        flush()                                         # a NaN loss raises here, before anything is written
+        if writer:
+            save_checkpoint(_checkpoint_state(model, optimizer, scaler, criterion, lr_scheduler, steps), steps, run_dir)
+            remove_extra_checkpoints(run_dir, keep=keep_checkpoints)
 
     for _ in range(epochs):
         for _i in tqdm(range(len(train_set))):
@@ -203,10 +217,8 @@ def training_loop(model, train_set, criterion, optimizer, lr_scheduler, logger, 
             steps_since_log += batch_size
             steps_since_checkpoint += batch_size
             it += 1
-            pending.append((recursive_cast(pred, lambda t: t.detach().argmax(-1)), y,
+            pending.append((logger, recursive_cast(pred, lambda t: t.detach().argmax(-1)), y,
                             recursive_cast(loss_dict, lambda t: t.detach())))
-            if len(pending) >= sync_every:
-                flush()
 
             if eval_set is not None and eval_logger is not None and it % eval_every == 0:
                 with torch.no_grad():
@@ -214,7 +226,9 @@ def training_loop(model, train_set, criterion, optimizer, lr_scheduler, logger, 
                     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(mixed_precision)):
                         ex, ey = recursive_cast(eval_set.get(), to_dev)
                         epred = model(ex)
-                    eval_logger.step.remote(recursive_cast(epred, lambda t: t.argmax(-1).cpu()), ey.cpu(), {})
+                    pending.append((eval_logger, recursive_cast(epred, lambda t: t.argmax(-1)), ey, {}))
+            if len(pending) >= sync_every:
+                flush()
 
             if steps_since_log // log_scalar_metric_step > 0:
                 flush()
@@ -224,14 +238,12 @@ def training_loop(model, train_set, criterion, optimizer, lr_scheduler, logger, 
                 steps_since_log = 0
 
             if steps_since_checkpoint // checkpoint_step > 0:
-                save_checkpoint(_checkpoint_state(model, optimizer, scaler, criterion, lr_scheduler, steps), steps, run_dir)
-                remove_extra_checkpoints(run_dir, keep=keep_checkpoints)
+                checkpoint()
                 steps_since_checkpoint = 0
             if max_steps is not None and it >= max_steps:
                 flush()
                 return steps
         flush()
         lr_scheduler.step()
-        save_checkpoint(_checkpoint_state(model, optimizer, scaler, criterion, lr_scheduler, steps), steps, run_dir)
-        remove_extra_checkpoints(run_dir, keep=keep_checkpoints)
+        checkpoint()
     return steps

@@ -109,12 +109,12 @@ def test_logger_and_metrics_duck_type():
 _DP_WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["MGX_ROOT"])
-from musicgeneration_amd.data_parallel import GradientBucketer
+from musicgeneration_amd.data_parallel import GradientBucketer, global_mean_denominator
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 torch.manual_seed(100 + rank)                       # different init per rank: the bucketer must broadcast rank 0's
 model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 4))
-ddp = GradientBucketer(model, bucket_mb=0.002)      # tiny buckets -> several of them
+ddp = GradientBucketer(model, bucket_mb=0.002, mode=MODE)      # tiny buckets -> several of them
 assert len(ddp.buckets) > 1
 g = torch.Generator().manual_seed(7)
 X = torch.randn(8, 16, generator=g); Y = torch.randn(8, 4, generator=g)
@@ -130,6 +130,17 @@ ref = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Lin
 for p, q in zip(model.parameters(), ref.parameters()):
     assert torch.allclose(p.detach(), q.detach()), "weights not broadcast"
     assert torch.allclose(p.grad, q.grad, atol=1e-6), "averaged gradient differs from the full-batch gradient"
+# weighted-mean losses: per-rank sum(w*nll) / global mean denominator averages to the loss of the whole batch
+from musicgeneration_amd import ops
+assert ops.LOSS_DENOMINATOR_HOOK is not None
+num = torch.tensor([3.0 + rank, 10.0 * (rank + 1)]); den = torch.tensor([2.0 + 3 * rank, 5.0 - rank])
+g = ops.LOSS_DENOMINATOR_HOOK(den)
+assert torch.allclose(g, global_mean_denominator(den))
+mine = num / g
+dist.all_reduce(mine)
+nums, dens = num.clone(), den.clone()
+dist.all_reduce(nums); dist.all_reduce(dens)
+assert torch.allclose(mine / world, nums / dens), (mine / world, nums / dens)
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
@@ -140,9 +151,8 @@ def test_gradient_bucketer_gloo_world2(tmp_path, mode):
     """Both exchange modes of the bucketer (grouped in-place all-reduce / packed flat buffers) with two ranks:
     averaged gradients equal the full-batch gradient of a single process, rank 0's weights are broadcast."""
     script = tmp_path / "dp_worker.py"
-    script.write_text(_DP_WORKER.replace("ddp = GradientBucketer(", "ddp = GradientBucketer(") +
-                      f"\nassert ddp.inplace == {mode == 'inplace'}\n")
-    env = dict(os.environ, MGX_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MGX_DP_MODE=mode)
+    script.write_text(_DP_WORKER.replace("MODE", repr(mode)) + f"\nassert ddp.inplace == {mode == 'inplace'}\n")
+    env = dict(os.environ, MGX_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", "29517" if mode == "flat" else "29519", str(script)],
                          env=env, capture_output=True, text=True, timeout=240)

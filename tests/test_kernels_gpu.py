@@ -699,3 +699,78 @@ def test_embedding_gemm_backward(V, d, T):
     ref = torch.zeros(V, d, dtype=torch.float64, device="cuda").index_add_(0, tok, dh.double())
     assert float((table.grad.double() - ref).abs().max()) < 1e-4 * max(1.0, (T / 3) ** 0.5)
     assert float(table.grad[tok.unique()].abs().sum()) > 0
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (300, 264, 192), (1024, 4096, 1024)])
+@pytest.mark.parametrize("act", ["gelu", "relu"])
+@pytest.mark.parametrize("p_drop", [0.0, 0.25])
+def test_gemm_nt_dact(M, N, K, act, p_drop):
+    """dgrad GEMM with the activation-backward epilogue == GEMM (bf16 output) followed by mgx_bias_act_bwd: same
+    rounding points, same dropout mask; the bias gradient equals the column sums of the rounded result."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(M, K, generator=g).bfloat16().cuda()
+    wt = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().cuda()
+    pre = torch.randn(M, N, generator=g).bfloat16().cuda()
+    seed = 4242
+    dpre, db = ops.gemm_nt_dact(dy, wt, pre, act, p_drop, seed)
+    dact = ops.gemm_nt(dy, wt)
+    want, want_db = ops.bias_act_bwd(dact, pre, act, p_drop, seed)
+    assert gu.rel_err(dpre.float(), want.float()) < 1e-2          # bf16 rounding of act' (two formulas of the same function)
+    assert float((dpre.float() - want.float()).abs().max()) <= 0.02 * float(want.float().abs().max())
+    assert gu.rel_err(db, dpre.float().sum(0)) < 1e-4
+    assert gu.rel_err(db, want_db) < 1e-2
+    if p_drop > 0:                                                # identical keep mask
+        assert torch.equal(dpre == 0, want == 0) or float(((dpre == 0) != (want == 0)).float().mean()) < 1e-3
+    # against the oracle formula in fp32
+    x = pre.float().cpu().requires_grad_(True)
+    y = torch.nn.functional.gelu(x) if act == "gelu" else torch.relu(x)
+    y.backward(torch.ones_like(y))
+    if p_drop == 0:
+        ref = dact.float().cpu() * x.grad
+        assert gu.rel_err(dpre.float(), ref) < BF16_TOL
+
+
+def test_embed_cat_matches_three_gathers():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    B, S = 3, 70
+    tabs = [torch.randn(92, 256, generator=g).cuda().requires_grad_(True), torch.randn(130, 256, generator=g).cuda().requires_grad_(True),
+            torch.randn(203, 512, generator=g).cuda().requires_grad_(True)]
+    x = torch.stack([torch.randint(0, 92, (B, S), generator=g), torch.randint(0, 130, (B, S), generator=g),
+                     torch.randint(0, 203, (B, S), generator=g)], 1).cuda()
+    out = ops.embed_cat_bf16(x, tuple(tabs))
+    want = torch.cat([torch.nn.functional.embedding(x[:, k], tabs[k]) for k in range(3)], -1).bfloat16()
+    assert torch.equal(out, want)
+    dh = torch.randn(B, S, 1024, generator=g).bfloat16().cuda()
+    out.backward(dh)
+    c0 = 0
+    for k, t in enumerate(tabs):
+        w = t.shape[1]
+        ref = torch.zeros_like(t).index_add_(0, x[:, k].reshape(-1), dh[..., c0:c0 + w].reshape(-1, w).float())
+        assert gu.rel_err(t.grad, ref) < 1e-5, k
+        c0 += w
+
+
+def test_softmax_xent_multi_equals_three_single_heads():
+    ops = _ops()
+    g = torch.Generator().manual_seed(8)
+    T, sizes = 200, (92, 130, 203)
+    ld = 448
+    logits = torch.randn(T, ld, generator=g).bfloat16().cuda()
+    ys = [torch.randint(0, v, (T,), generator=g).cuda() for v in sizes]
+    ys[2][::7] = 1
+    wn = torch.ones(92).cuda(); wn[1] = 0; wn[2] = 0.05
+    wv = torch.ones(130).cuda(); wv[1] = 0; wv[2] = 0.05
+    heads = ((ys[0], wn, None, 0, 92), (ys[1], wv, None, 92, 130), (ys[2], None, 1, 222, 203))
+    coef = (1.0, 0.5, 2.0)
+    a = logits.clone().requires_grad_(True)
+    la = ops.softmax_cross_entropy_multi(a, heads)
+    sum(c * l for c, l in zip(coef, la)).backward()
+    b = logits.clone().requires_grad_(True)
+    lb = [ops.softmax_cross_entropy(b, y, w, ii, col0=c0, V=v) for y, w, ii, c0, v in heads]
+    sum(c * l for c, l in zip(coef, lb)).backward()
+    for u, v in zip(la, lb):
+        assert float(u) == float(v)
+    assert torch.equal(a.grad, b.grad)
+    assert float(a.grad[:, 425:].abs().max()) == 0.0

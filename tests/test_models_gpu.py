@@ -429,6 +429,42 @@ def test_training_loop_end_to_end(tmp_path):
     assert torch.equal(m2.state_dict()["embed.weight"], state["model"]["embed.weight"])
 
 
+def test_nan_loss_never_reaches_a_checkpoint(tmp_path):
+    """A NaN loss is detected at the deferred sync point (train_utils.py:168 asserts every step); the loop flushes
+    before every checkpoint, so no <step>.tar is written once a NaN step has happened."""
+    from musicgeneration_amd.model_baseline.alibi_unified import AlibiTransformer, Criterion, Metrics
+    from musicgeneration_amd import train_utils as tu
+    from musicgeneration_amd.synthetic import SyntheticUnifiedDataset
+    torch.manual_seed(0)
+    m = AlibiTransformer(vocab=618, embed_dim=64, n_layers=1, n_heads=4, max_sequence=64, proj_forward=128, dropout=0.0).cuda()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.StepLR(opt, 50)
+
+    class Poisoned(Criterion):
+        calls = 0
+        def forward(self, xs, y):
+            loss, d = super().forward(xs, y)
+            Poisoned.calls += 1
+            if Poisoned.calls == 3:
+                loss = loss * float("nan")
+                d = {"loss": loss}
+            return loss, d
+
+    class Data:
+        def __init__(self):
+            self.b = SyntheticUnifiedDataset(2, 32, seed=5).get()
+        def __len__(self):
+            return 40
+        def get(self):
+            return self.b
+
+    with pytest.raises(AssertionError, match="NaN"):
+        tu.training_loop(m, Data(), Poisoned(1).cuda(), opt, sched, tu.Logger(None, Metrics()), log_scalar_metric_step=10 ** 6,
+                         checkpoint_step=10, epochs=1, batch_size=2, run_dir=str(tmp_path), sync_every=16)
+    # checkpoint_step 10 samples = every 5 iterations: the first save would come at iteration 5, after the NaN of 3
+    assert tu.get_checkpoints(str(tmp_path)) == []
+
+
 def test_dropout_training_mode_runs_and_differs():
     from musicgeneration_amd.model_baseline.alibi_unified import AlibiTransformer
     torch.manual_seed(1)
@@ -543,11 +579,12 @@ def test_bench_data_parallel_path_on_rccl():
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--seq", "512",
            "--no-cpu-baseline"]
     lines = []
-    for force in ("0", "1"):
-        env = dict(os.environ, MGX_BENCH_FORCE_DP=force, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110, cwd=root)
+    for extra in ([], ["--force-dp"], ["--force-dp", "--dp-mode", "inplace"]):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+        r = subprocess.run(cmd + extra, env=env, capture_output=True, text=True, timeout=110, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         lines.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    assert abs(lines[0]["final_loss"] - lines[2]["final_loss"]) < 2e-2
     assert lines[0]["n_gpus"] == lines[1]["n_gpus"] == 1
     assert np.isfinite(lines[1]["final_loss"])
     assert abs(lines[0]["final_loss"] - lines[1]["final_loss"]) < 2e-2      # dropout masks are seeded; bf16 step
