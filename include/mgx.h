@@ -28,6 +28,9 @@ extern "C" {
 #endif
 
 enum { MGX_F32 = 0, MGX_BF16 = 1 };
+/* OR-ed into the `dtype` argument of the attention entry points: run the generic wave-per-row kernels even where the
+ * MFMA kernels apply (tests and diagnostics; a per-call request, the library keeps no mutable state). */
+enum { MGX_GENERIC_KERNELS = 0x100 };
 enum { MGX_ACT_GELU = 0, MGX_ACT_RELU = 1 };
 enum { MGX_OK = 0, MGX_EINVAL = -1, MGX_EUNSUPPORTED = -2, MGX_ELAUNCH = -3 };
 
@@ -295,10 +298,6 @@ int mgx_separated_decode_events(const int* tokens, int B, int L, const int* dur_
 int mgx_unified_encode_tokens(const int* notes, const int* velocities, const int* durations, const int* lengths,
                               const int* starts, int B, int Nmax, int seq_len, int note_bins, int velocity_bins,
                               int duration_bins, int* tokens, void* stream);
-
-/* Test hook (no reference counterpart): route attention through the generic
- * kernels (on != 0) or restore the MFMA dispatch (on == 0). */
-void mgx_debug_force_generic_attention(int on);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 F32, BF16 = 0, 1
+GENERIC_KERNELS = 0x100        # OR-ed into an attention call's dtype: generic kernels (tests)
 ACT_GELU, ACT_RELU = 0, 1
 
 _vp, _i, _l, _f, _u64, _ll = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_ulonglong, C.c_longlong
@@ -59,7 +60,6 @@ PROTOTYPES = {
     "mgx_gemm_nt_dact_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _vp]),
     "mgx_gemm_tn_workspace_floats": (_l, [_i, _i, _i, _vp]),
     "mgx_gemm_tn_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "mgx_debug_force_generic_attention": (None, [_i]),
 }
 
 for _name, (_res, _args) in PROTOTYPES.items():

@@ -28,12 +28,16 @@ int mgx_attn_bwd_mfma(int mode, const void* dout, const void* qkv, const void* o
                       const float* slopes, const void* E, void* dqkv, float* dE, float* delta, int B, int S, int H,
                       int dh, int max_seq, hipStream_t st);
 
-static int g_force_generic = 0;
-// Test hook: route every attention call through the generic kernels (1) or restore dispatch (0).
-extern "C" void mgx_debug_force_generic_attention(int on) { g_force_generic = on; }
+// dtype | MGX_GENERIC_KERNELS: per-call request for the generic (non-MFMA) kernels (tests, diagnostics)
+static inline bool take_generic_flag(int& dtype) {
+    const bool g = (dtype & MGX_GENERIC_KERNELS) != 0;
+    dtype &= ~MGX_GENERIC_KERNELS;
+    return g;
+}
 
 extern "C" int mgx_alibi_attn_fwd(const void* qkv, const float* slopes, void* out, float* lse, int B, int S, int H,
                                   int dh, int dtype, void* stream) {
+    const bool g_force_generic = take_generic_flag(dtype);
     MGX_REQUIRE(qkv && slopes && out && lse, MGX_EINVAL, "mgx_alibi_attn_fwd: null pointer");
     int rc = mgx_check_attn_shape("mgx_alibi_attn_fwd", B, S, H, dh, dtype);
     if (rc) return rc;
@@ -45,6 +49,7 @@ extern "C" int mgx_alibi_attn_fwd(const void* qkv, const float* slopes, void* ou
 extern "C" int mgx_alibi_attn_bwd(const void* dout, const void* qkv, const void* out, const float* lse,
                                   const float* slopes, void* dqkv, float* delta, int B, int S, int H, int dh,
                                   int dtype, void* stream) {
+    const bool g_force_generic = take_generic_flag(dtype);
     MGX_REQUIRE(dout && qkv && out && lse && slopes && dqkv && delta, MGX_EINVAL, "mgx_alibi_attn_bwd: null pointer");
     int rc = mgx_check_attn_shape("mgx_alibi_attn_bwd", B, S, H, dh, dtype);
     if (rc) return rc;
@@ -57,6 +62,7 @@ extern "C" int mgx_alibi_attn_bwd(const void* dout, const void* qkv, const void*
 
 extern "C" int mgx_rel_attn_fwd(const void* qkv, const void* E, void* out, float* lse, int B, int S, int H, int dh,
                                 int max_seq, int dtype, void* stream) {
+    const bool g_force_generic = take_generic_flag(dtype);
     MGX_REQUIRE(qkv && E && out && lse, MGX_EINVAL, "mgx_rel_attn_fwd: null pointer");
     int rc = mgx_check_attn_shape("mgx_rel_attn_fwd", B, S, H, dh, dtype);
     if (rc) return rc;
@@ -69,6 +75,7 @@ extern "C" int mgx_rel_attn_fwd(const void* qkv, const void* E, void* out, float
 extern "C" int mgx_rel_attn_bwd(const void* dout, const void* qkv, const void* out, const float* lse, const void* E,
                                 void* dqkv, float* dE, float* delta, int B, int S, int H, int dh, int max_seq,
                                 int dtype, void* stream) {
+    const bool g_force_generic = take_generic_flag(dtype);
     MGX_REQUIRE(dout && qkv && out && lse && E && dqkv && dE && delta, MGX_EINVAL, "mgx_rel_attn_bwd: null pointer");
     int rc = mgx_check_attn_shape("mgx_rel_attn_bwd", B, S, H, dh, dtype);
     if (rc) return rc;

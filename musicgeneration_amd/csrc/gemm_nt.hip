@@ -97,7 +97,7 @@ __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 
         __builtin_amdgcn_sched_barrier(0);                     \
     } while (0)
 
-template <int EPI, int ACT, bool DROP, bool STAGGER>
+template <int EPI, int ACT, bool DROP>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[2 * LDS_B];
     typedef __attribute__((address_space(3))) void lds_void;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
     stage_b(0, 1, 1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // A0(0), B0(0), B1(0) landed
     NT_BAR();
-    if (STAGGER && wr == 1) NT_BAR();
+    if (wr == 1) NT_BAR();                                     // waves 4-7 run one barrier behind waves 0-3
 
     auto tile_step = [&](auto dtag, int t) {
         constexpr int d = decltype(dtag)::value;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
         if (t + 1 < nk) tile_step(std::integral_constant<int, 1>{}, t + 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the clamped re-loads of the last K tiles
-    if (STAGGER && wr == 0) NT_BAR();
+    if (wr == 0) NT_BAR();
 #undef NT_MMA
 
     // ---- epilogue from the accumulators -----------------------------------------------------------------
@@ -417,7 +417,7 @@ static int nt_check(const char* fn, const void* A, const void* Bt, const void* C
 }
 
 #define NT_LAUNCH(EPI, ACT, DROP)                                                                              \
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, ACT, DROP, true>), dim3((unsigned)nblk), dim3(NTHREADS), 0,        \
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, ACT, DROP>), dim3((unsigned)nblk), dim3(NTHREADS), 0,              \
                        (hipStream_t)stream, g)
 
 extern "C" int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2, const float* bias, const void* res,
@@ -455,19 +455,5 @@ extern "C" int mgx_gemm_nt_dact_bf16(const void* A, const void* Bt, const void* 
     if (act == MGX_ACT_GELU) { if (drop) NT_LAUNCH(EPI_DACT, MGX_ACT_GELU, true); else NT_LAUNCH(EPI_DACT, MGX_ACT_GELU, false); }
     else { if (drop) NT_LAUNCH(EPI_DACT, MGX_ACT_RELU, true); else NT_LAUNCH(EPI_DACT, MGX_ACT_RELU, false); }
     MGX_CHECK_LAUNCH("gemm_nt_dact");
-    return MGX_OK;
-}
-
-// lab entry (tools/gemm_lab): variant 0 = staggered wave groups, 1 = both groups in lockstep
-extern "C" int mgx_gemm_nt_lab(const void* A, const void* Bt, void* C, const float* bias, int M, int N, int K, int variant,
-                               void* stream) {
-    if (int rc = nt_check("mgx_gemm_nt_lab", A, Bt, C, M, N, K, K, K, N)) return rc;
-    NtArgs g{(const char*)A, (const char*)Bt, (bf16_t*)C, nullptr, bias, nullptr, nullptr, nullptr, M, N, K, K, K, N, 0.f, 0ull};
-    const long nblk = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    if (variant == 0)
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI_PLAIN, 0, false, true>), dim3((unsigned)nblk), dim3(NTHREADS), 0, (hipStream_t)stream, g);
-    else
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI_PLAIN, 0, false, false>), dim3((unsigned)nblk), dim3(NTHREADS), 0, (hipStream_t)stream, g);
-    MGX_CHECK_LAUNCH("gemm_nt_lab");
     return MGX_OK;
 }

@@ -78,8 +78,12 @@ def new_seed() -> int:
 # ---------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------
-def alibi_attn_fwd(qkv: torch.Tensor, slopes: torch.Tensor, n_heads: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """qkv [B,S,3*d] -> (out [B,S,d], lse [B,H,S])."""
+def _attn_dt(t, generic):
+    return _dt(t) | (_lib.GENERIC_KERNELS if generic else 0)
+
+
+def alibi_attn_fwd(qkv: torch.Tensor, slopes: torch.Tensor, n_heads: int, generic: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """qkv [B,S,3*d] -> (out [B,S,d], lse [B,H,S]).  generic=True: the wave-per-row kernels even where MFMA applies."""
     _need(qkv, "qkv")
     _need(slopes, "slopes", torch.float32)
     B, S, d3 = qkv.shape
@@ -89,12 +93,12 @@ def alibi_attn_fwd(qkv: torch.Tensor, slopes: torch.Tensor, n_heads: int) -> Tup
     out = torch.empty(B, S, d, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, n_heads, S, dtype=torch.float32, device=qkv.device)
     with _timed("alibi_attn_fwd", 2.0 * B * n_heads * S * S * (d // n_heads)):
-        check(lib.mgx_alibi_attn_fwd(_p(qkv), _p(slopes), _p(out), _p(lse), B, S, n_heads, d // n_heads, _dt(qkv),
-                                     _stream()), "mgx_alibi_attn_fwd")
+        check(lib.mgx_alibi_attn_fwd(_p(qkv), _p(slopes), _p(out), _p(lse), B, S, n_heads, d // n_heads,
+                                     _attn_dt(qkv, generic), _stream()), "mgx_alibi_attn_fwd")
     return out, lse
 
 
-def alibi_attn_bwd(dout, qkv, out, lse, slopes, n_heads: int) -> torch.Tensor:
+def alibi_attn_bwd(dout, qkv, out, lse, slopes, n_heads: int, generic: bool = False) -> torch.Tensor:
     _need(dout, "dout", qkv.dtype)
     B, S, d3 = qkv.shape
     d = d3 // 3
@@ -104,11 +108,11 @@ def alibi_attn_bwd(dout, qkv, out, lse, slopes, n_heads: int) -> torch.Tensor:
     delta = torch.empty_like(lse)
     with _timed("alibi_attn_bwd", 5.0 * B * n_heads * S * S * (d // n_heads)):      # 5 products at half the square
         check(lib.mgx_alibi_attn_bwd(_p(dout), _p(qkv), _p(out), _p(lse), _p(slopes), _p(dqkv), _p(delta), B, S, n_heads,
-                                     d // n_heads, _dt(qkv), _stream()), "mgx_alibi_attn_bwd")
+                                     d // n_heads, _attn_dt(qkv, generic), _stream()), "mgx_alibi_attn_bwd")
     return dqkv
 
 
-def rel_attn_fwd(qkv: torch.Tensor, E: torch.Tensor, n_heads: int):
+def rel_attn_fwd(qkv: torch.Tensor, E: torch.Tensor, n_heads: int, generic: bool = False):
     _need(qkv, "qkv")
     _need(E, "E", qkv.dtype)
     B, S, d3 = qkv.shape
@@ -119,12 +123,12 @@ def rel_attn_fwd(qkv: torch.Tensor, E: torch.Tensor, n_heads: int):
     out = torch.empty(B, S, d, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, S, dtype=torch.float32, device=qkv.device)
     with _timed("rel_attn_fwd", 3.0 * B * H * S * S * dh):
-        check(lib.mgx_rel_attn_fwd(_p(qkv), _p(E), _p(out), _p(lse), B, S, H, dh, M, _dt(qkv), _stream()),
+        check(lib.mgx_rel_attn_fwd(_p(qkv), _p(E), _p(out), _p(lse), B, S, H, dh, M, _attn_dt(qkv, generic), _stream()),
               "mgx_rel_attn_fwd")
     return out, lse
 
 
-def rel_attn_bwd(dout, qkv, out, lse, E, n_heads: int):
+def rel_attn_bwd(dout, qkv, out, lse, E, n_heads: int, generic: bool = False):
     _need(dout, "dout", qkv.dtype)
     B, S, d3 = qkv.shape
     H, M, dh = E.shape
@@ -133,7 +137,7 @@ def rel_attn_bwd(dout, qkv, out, lse, E, n_heads: int):
     delta = torch.empty_like(lse)
     with _timed("rel_attn_bwd", 6.0 * B * H * S * S * dh):      # dV, dP, dQ (two terms), dK, dE at half the square
         check(lib.mgx_rel_attn_bwd(_p(dout), _p(qkv), _p(out), _p(lse), _p(E), _p(dqkv), _p(dE), _p(delta), B, S, H, dh, M,
-                                   _dt(qkv), _stream()), "mgx_rel_attn_bwd")
+                                   _attn_dt(qkv, generic), _stream()), "mgx_rel_attn_bwd")
     return dqkv, dE
 
 

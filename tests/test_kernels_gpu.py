@@ -71,7 +71,6 @@ def test_alibi_attention_fp32(B, S, H, dh):
 @pytest.mark.parametrize("force_generic", [False, True])
 def test_alibi_attention_bf16(B, S, H, dh, force_generic):
     ops = _ops()
-    from musicgeneration_amd._lib import lib
     g = torch.Generator().manual_seed(S * 7 + dh)
     qkv = torch.randn(B, S, 3 * H * dh, generator=g).bfloat16()
     dout = torch.randn(B, S, H * dh, generator=g).bfloat16()
@@ -79,12 +78,8 @@ def test_alibi_attention_bf16(B, S, H, dh, force_generic):
     ref_in = qkv.float().requires_grad_(True)
     ref = _ref_attn(ref_in, H)
     ref.backward(dout.float())
-    lib.mgx_debug_force_generic_attention(1 if force_generic else 0)
-    try:
-        out, lse = ops.alibi_attn_fwd(qkv.cuda(), slopes.cuda(), H)
-        dqkv = ops.alibi_attn_bwd(dout.cuda(), qkv.cuda(), out, lse, slopes.cuda(), H)
-    finally:
-        lib.mgx_debug_force_generic_attention(0)
+    out, lse = ops.alibi_attn_fwd(qkv.cuda(), slopes.cuda(), H, generic=force_generic)
+    dqkv = ops.alibi_attn_bwd(dout.cuda(), qkv.cuda(), out, lse, slopes.cuda(), H, generic=force_generic)
     assert gu.rel_err(out.float(), ref) < BF16_TOL
     assert gu.rel_err(dqkv.float(), ref_in.grad) < BF16_TOL
 
@@ -160,7 +155,6 @@ def test_relative_attention_bf16_mfma(B, S, H, dh, M, force_generic):
     """Skew relative attention on the MFMA path (ring skew through LDS, dE band kernel) and on the
     generic path, against the oracle's pad/reshape skew in fp32 on the same bf16-rounded inputs."""
     ops = _ops()
-    from musicgeneration_amd._lib import lib
     g = torch.Generator().manual_seed(S * 3 + dh + M)
     qkv = torch.randn(B, S, 3 * H * dh, generator=g).bfloat16()
     E = (0.5 * torch.randn(H, M, dh, generator=g)).bfloat16()
@@ -169,12 +163,8 @@ def test_relative_attention_bf16_mfma(B, S, H, dh, M, force_generic):
     ref_E = E.float().requires_grad_(True)
     ref = _ref_attn(ref_in, H, E=ref_E, max_seq=M)
     ref.backward(dout.float())
-    lib.mgx_debug_force_generic_attention(1 if force_generic else 0)
-    try:
-        out, lse = ops.rel_attn_fwd(qkv.cuda(), E.cuda(), H)
-        dqkv, dE = ops.rel_attn_bwd(dout.cuda(), qkv.cuda(), out, lse, E.cuda(), H)
-    finally:
-        lib.mgx_debug_force_generic_attention(0)
+    out, lse = ops.rel_attn_fwd(qkv.cuda(), E.cuda(), H, generic=force_generic)
+    dqkv, dE = ops.rel_attn_bwd(dout.cuda(), qkv.cuda(), out, lse, E.cuda(), H, generic=force_generic)
     assert gu.rel_err(out.float(), ref) < BF16_TOL
     q, k, _ = (O._heads(t, H) for t in torch.split(qkv.float(), H * dh, dim=2))
     w = (q @ k.transpose(-1, -2) + O.skew_relative_logits(q, E.float(), M)) / math.sqrt(dh) + O.causal_mask(S)

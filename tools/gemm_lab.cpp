@@ -13,7 +13,6 @@
 extern "C" {
 int mgx_gemm_nt_bf16(const void*, const void*, void*, void*, const float*, const void*, int, int, int, int, int, int, int,
                      float, unsigned long long, void*);
-int mgx_gemm_nt_lab(const void*, const void*, void*, const float*, int, int, int, int, void*);
 long mgx_gemm_tn_workspace_floats(int, int, int, int*);
 int mgx_gemm_tn_bf16(const void*, const void*, void*, float*, int, int, int, int, int, int, void*);
 const char* mgx_last_error_string(void);
@@ -124,11 +123,9 @@ static void run_nt(int M, int N, int K, int rounds, int reps) {
     std::vector<float> href((size_t)NR * N);
     CK(hipMemcpy(href.data(), ref, href.size() * 4, hipMemcpyDeviceToHost));
 
-    std::vector<Variant> vs = {{"nt8_stagger", 1}, {"nt8_lockstep", 2}, {"nt8_bias(entry)", 3}, {"nt8_gelu_drop(entry)", 4}};
+    std::vector<Variant> vs = {{"nt_bias", 3}, {"nt_gelu_drop", 4}};
     auto launch = [&](const Variant& v) -> int {
         switch (v.kind) {
-            case 1: return mgx_gemm_nt_lab(A, Bt, C, bias, M, N, K, 0, nullptr);
-            case 2: return mgx_gemm_nt_lab(A, Bt, C, bias, M, N, K, 1, nullptr);
             case 3: return mgx_gemm_nt_bf16(A, Bt, C, nullptr, bias, nullptr, M, N, K, K, K, N, -1, 0.f, 0, nullptr);
             default: return mgx_gemm_nt_bf16(A, Bt, C, C2, bias, nullptr, M, N, K, K, K, N, 0, 0.1f, 1234, nullptr);
         }
