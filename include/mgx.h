@@ -215,6 +215,17 @@ int mgx_embed_cat_bf16(const long long* tokens, int n, int B, int S, const float
 long mgx_colsum_workspace_floats(int n);
 int mgx_colsum_bf16(const void* x, float* out, float* workspace, long T, int n, void* stream);
 
+/* The same column sums with NO workspace argument and no allocation of any kind (no hipMalloc / hipFree, no
+ * allocating library routine): it has no counterpart in the reference and exists for callers that cannot allocate —
+ * code under HIP-graph capture, tight serving loops, harnesses that forbid hipMalloc.  The stage-1 partial sums live in
+ * a device array inside the library: 128 x 8192 floats = 4 MiB on every GPU the library runs on, held until the
+ * process ends.  n <= mgx_colsum_static_max_n() (8192; wider matrices are rejected with MGX_EUNSUPPORTED: use
+ * mgx_colsum_bf16 with a workspace).  Results are bit-identical to mgx_colsum_bf16.  All calls on one GPU share that
+ * GPU's array: calls that overlap in time on one GPU (two streams, two threads) race; calls on one stream do not.
+ * The first call on a device looks up the array's address (hipGetSymbolAddress): make it outside graph capture. */
+int mgx_colsum_static_max_n(void);
+int mgx_colsum_bf16_static(const void* x, float* out, long T, int n, void* stream);
+
 /* bf16 shadows of fp32 master weights (the `.to(x.dtype)` of every autocast projection, and the transposed
  * operand the GEMM libraries prefer): master [rows, cols] fp32 -> dst [rows, cols] bf16 and/or dst_t
  * [cols, rows] bf16 in one pass over the master.  `count` matrices per call (HOST arrays of device pointers;

@@ -54,6 +54,8 @@ PROTOTYPES = {
     "mgx_embed_cat_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "mgx_colsum_workspace_floats": (_l, [_i]),
     "mgx_colsum_bf16": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
+    "mgx_colsum_static_max_n": (_i, []),
+    "mgx_colsum_bf16_static": (_i, [_vp, _vp, _l, _i, _vp]),
     "mgx_cast_shadow_bf16": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mgx_gemm_nt_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _vp]),
     "mgx_gemm_nt_dact_colpart_floats": (_l, [_i, _i]),

@@ -7,6 +7,7 @@
 // vector accesses (8 bf16 or 4 fp32 per lane per step), row held in registers
 // between the statistics pass and the normalise pass so each element is read once.
 #include "mgx_common.h"
+#include <mutex>
 
 namespace {
 
@@ -864,6 +865,55 @@ extern "C" int mgx_cast_shadow_bf16(int count, const float* const* src, void* co
 }
 
 extern "C" long mgx_colsum_workspace_floats(int n) { return n > 0 ? (long)COLSUM_CHUNKS * n : 0; }
+
+// ---- mgx_colsum_bf16_static: the same reduction without a caller-provided workspace ----------------------------
+// For callers that cannot allocate (HIP-graph capture, serving loops, harnesses that forbid hipMalloc): the stage-1
+// partial sums live in a file-scope device array, 4 MiB per GPU for the life of the process.  In host code the
+// array's name is only a stand-in (not a device address): its address on the CURRENT device is looked up once per
+// device with hipGetSymbolAddress and that pointer is what the kernels receive.
+constexpr int COLSUM_STATIC_MAX_N = 8192;
+static __device__ __align__(256) float scratch[COLSUM_CHUNKS * COLSUM_STATIC_MAX_N];
+constexpr int MGX_MAX_DEVICES = 64;
+static float* g_scratch_ptr[MGX_MAX_DEVICES] = {};
+static std::mutex g_scratch_mutex;
+
+static int colsum_static_scratch(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    MGX_REQUIRE(e == hipSuccess && dev >= 0 && dev < MGX_MAX_DEVICES, MGX_ELAUNCH,
+                "mgx_colsum_bf16_static: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        float* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));       // this device's copy of the array
+        MGX_REQUIRE(e == hipSuccess && p, MGX_ELAUNCH, "mgx_colsum_bf16_static: hipGetSymbolAddress: %s",
+                    hipGetErrorString(e));
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return MGX_OK;
+}
+
+extern "C" int mgx_colsum_static_max_n(void) { return COLSUM_STATIC_MAX_N; }
+
+extern "C" int mgx_colsum_bf16_static(const void* x, float* out, long T, int n, void* stream) {
+    MGX_REQUIRE(x && out, MGX_EINVAL, "mgx_colsum_bf16_static: null pointer");
+    MGX_REQUIRE(T > 0 && n > 0 && n % 8 == 0, MGX_EUNSUPPORTED, "mgx_colsum_bf16_static: T=%ld n=%d (n must be a multiple of 8)", T, n);
+    MGX_REQUIRE(n <= COLSUM_STATIC_MAX_N, MGX_EUNSUPPORTED,
+                "mgx_colsum_bf16_static: n=%d exceeds the static scratch (at most %d columns; use mgx_colsum_bf16 with a "
+                "workspace for wider matrices)", n, COLSUM_STATIC_MAX_N);
+    float* ws = nullptr;
+    if (int rc = colsum_static_scratch(&ws)) return rc;
+    // every partial the second stage reads is written by the first (all COLSUM_CHUNKS rows of its n columns): nothing
+    // has to start at zero, whatever an earlier (larger) call left behind
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((n + 511) / 512, COLSUM_CHUNKS), dim3(256), 0, st, (const bf16_t*)x,
+                       ws, T, n);
+    MGX_CHECK_LAUNCH("colsum_partial");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, out, n);
+    MGX_CHECK_LAUNCH("colsum_final");
+    return MGX_OK;
+}
 
 extern "C" int mgx_colsum_bf16(const void* x, float* out, float* workspace, long T, int n, void* stream) {
     MGX_REQUIRE(x && out && workspace, MGX_EINVAL, "mgx_colsum_bf16: null pointer");
