@@ -1,18 +1,19 @@
 #!/usr/bin/env python3
-"""Headline benchmark: training tokens/s of the fused ALiBi transformer step.
+"""Headline benchmark: training tokens/s of the fused ALiBi transformer step + decode tokens/s.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train_unified|train_separated|
                      train_relative|decode_unified] [--batch B] [--seq S] [--dtype bf16|fp32]
 
-One "step" = one full training step (forward, fused softmax-CE, backward,
-gradient all-reduce when N>1, fused AdamW) on one batch of synthetic MIDI-grammar
-tokens already resident in HBM.  N=1 default workload = BASELINE.json configs[1]:
-alibi_unified d=1024 L=6 H=8 ff=4096 V=618, bf16, seq 2048, batch 16 per GPU.
+One "step" = one full training step (forward, fused softmax-CE, backward, gradient all-reduce when N>1,
+fused AdamW) on one batch of synthetic MIDI-grammar tokens already resident in HBM.  N=1 default workload =
+BASELINE.json configs[1]: alibi_unified d=1024 L=6 H=8 ff=4096 V=618, bf16, seq 2048, batch 16 per GPU.
 For N>1 launch under torch.distributed.run (one rank per GPU, RCCL); weak scaling.
 
-Rank 0 prints ONE JSON line with the metric, the roofline of the dominant libmgx
-kernel (HIP-event timed inside the timed region) and the CPU baseline (the
-oracle's restatement of the reference step on the host cores, rank 0, N=1 only).
+Rank 0 prints ONE JSON line: the training metric; `roofline` = the kernel with the largest share of the step
+(HIP-event timed inside the timed region; every other MFMA kernel in `roofline_other_kernels`); `decode` = the
+second half of BASELINE.json's metric (configs[3]: KV-cached greedy sampling, batch 64, 4096-token continuation:
+tokens/s, fraction of the HBM roofline for the whole step and for the decode-attention kernel); `cpu_baseline` = the
+oracle's restatement of the reference step on the host cores (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -28,6 +29,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0         # HBM3E spec, same table
+TRAFFIC_FILE = "r02_traffic_pmc.json"
 
 
 def pmc_traffic(key):
@@ -35,7 +37,7 @@ def pmc_traffic(key):
     FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs, read side doubled as MI355X_MICROARCH.md's HBM
     section prescribes for gfx950).  None when no measurement exists for this exact kernel configuration."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
             t = json.load(f)
         return float(t[key]["hbm_bytes_corrected"])
     except (OSError, KeyError, ValueError):
@@ -48,7 +50,6 @@ def fwd_flops_per_token(L, d, ff, S, V, s_eff_factor=1.0):
 
 
 def build_workload(name, batch, seq, dtype, device):
-    from musicgeneration_amd.misc import EasyDict
     from musicgeneration_amd.synthetic import SyntheticSeparatedDataset, SyntheticUnifiedDataset
     rank = int(os.environ.get("RANK", "0"))
     if name == "train_unified":
@@ -76,9 +77,8 @@ def build_workload(name, batch, seq, dtype, device):
         shape = (args.n_heads, d // args.n_heads, args.n_layers)
     elif name == "train_relative":
         from musicgeneration_amd.old_models.relative_transformer import RelativeTransformer
-        model = RelativeTransformer(618, 512, 6, 8, max(seq, 4096), 2048, dropout=0.1, dtype=dtype)
-
         from musicgeneration_amd.model_baseline.alibi_unified import Criterion
+        model = RelativeTransformer(618, 512, 6, 8, max(seq, 4096), 2048, dropout=0.1, dtype=dtype)
         crit = Criterion(None)                                   # plain mean CE (old_models/train.py's loss)
         data = SyntheticUnifiedDataset(batch, seq, seed=1234 + rank, device=device)
         fl = fwd_flops_per_token(6, 512, 2048, seq, 618, 1.5)
@@ -90,11 +90,31 @@ def build_workload(name, batch, seq, dtype, device):
     return model.to(device), crit.to(device), data, fl, desc, lr, wd, shape
 
 
-def cpu_baseline(steps=3, warmup=1):
-    """the oracle (CPU restatement of the reference, parity-pinned by golden vectors)
-    runs config 1 — unified d=512 L=6 H=8 ff=4096, fp32, batch 8 x seq 1024, fwd+loss+bwd+AdamW."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            info = f.read()
+    except OSError:
+        return "unknown", None
+    model = next((l.split(":", 1)[1].strip() for l in info.splitlines() if l.startswith("model name")), "unknown")
+    cores = set()
+    phys = None
+    for l in info.splitlines():
+        if l.startswith("physical id"):
+            phys = l.split(":")[1].strip()
+        elif l.startswith("core id"):
+            cores.add((phys, l.split(":")[1].strip()))
+    return model, (len(cores) or None)
+
+
+def cpu_baseline(steps=5, warmup=2):
+    """the oracle (CPU restatement of the reference, parity-pinned by golden vectors) runs config 1
+    — unified d=512 L=6 H=8 ff=4096, fp32, batch 8 x seq 1024, dropout 0.1, fwd + loss + bwd + AdamW(1e-3, wd 1e-4):
+    2 warm-up + 5 timed steps, median.  Threads: torch's default on the box (its CPU share: OMP_NUM_THREADS), which
+    is what `cores` reports; the machine's physical core count and CPU model ride along in `sample`."""
     from oracle import reference_port as O
     threads = torch.get_num_threads()
+    model, phys = _cpu_model()
     g = torch.Generator().manual_seed(1234)
     V, d, L, H, ff, B, S = 618, 512, 6, 8, 4096, 8, 1024
     sd = {"embed.weight": torch.randn(V, d, generator=g), "norm.g": torch.ones(d), "norm.b": torch.zeros(d),
@@ -114,14 +134,15 @@ def cpu_baseline(steps=3, warmup=1):
     times = []
     for it in range(warmup + steps):
         t0 = time.perf_counter()
-        O.unified_train_step(sd, opt, x, y, H, pad_index=1)
+        O.unified_train_step(sd, opt, x, y, H, pad_index=1, p_drop=0.1)
         if it >= warmup:
             times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
     return {"value": B * S / med, "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"oracle fp32 train step, unified d=512 L=6 S=1024 batch 8 (configs[0]), {steps} timed steps "
-                      f"after {warmup} warm-up, median {med:.2f} s/step, dropout off"}
+            "sample": f"oracle fp32 train step, unified d=512 L=6 S=1024 batch 8 (configs[0]), dropout 0.1, AdamW; "
+                      f"{steps} timed steps after {warmup} warm-up, median {med:.2f} s/step; {threads} torch threads on "
+                      f"'{model}' (os.cpu_count()={os.cpu_count()}, physical cores={phys})"}
 
 
 def main():
@@ -134,6 +155,7 @@ def main():
     ap.add_argument("--seq", type=int, default=None)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode half of the metric")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel path (RCCL group, gradient bucketer) with one rank: its test on a one-GPU box")
     ap.add_argument("--dp-mode", default="flat", choices=["flat", "inplace"], help="GradientBucketer exchange mode")
@@ -159,7 +181,12 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     if a.workload == "decode_unified":
-        return bench_decode(a, device, rank, world)
+        out = bench_decode(a, device, rank, world, a.batch or 64, a.seq or 4096)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     defaults = {"train_unified": (16, 2048), "train_separated": (8, 1024), "train_relative": (8, 4096)}[a.workload]
     B = a.batch or defaults[0]
@@ -192,8 +219,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # HIP-event pairs around the hand-written MFMA kernels' launches, inside the timed region, on the first
-    # EVENT_STEPS steps only (84 event records per step cost ~0.2 ms of the step they bracket)
+    # HIP-event pairs around the MFMA kernels' launches, inside the timed region, on the first EVENT_STEPS steps
+    # only (~100 event pairs per step cost ~0.2 ms of the step they bracket)
     EVENT_STEPS = min(3, a.steps)
     events = ops.KERNEL_EVENTS = {}
     t0 = time.perf_counter()
@@ -216,16 +243,19 @@ def main():
     tokens = world * B * S * a.steps
     value = tokens / dt
     train_fl = 3 * fwd_fl
-    # roofline: every hand-written MFMA kernel that is timed by a HIP-event pair around its launches inside the
-    # timed region (musicgeneration_amd.ops._timed, on the stream the kernels run on); the headline `roofline`
-    # object is the one with the largest total time.  achieved = algorithmic FLOPs of the launches / their time.
+    # roofline: every MFMA kernel of the step is one of libmgx's and is timed by a HIP-event pair around its launches
+    # inside the timed region (musicgeneration_amd.ops._timed, on the stream the kernels run on); the headline
+    # `roofline` object is the one with the largest total time.  achieved = algorithmic FLOPs of the launches / their time.
     labels = {"alibi_attn_fwd": "attn_fwd_mfma_kernel (ALiBi flash forward; QK^T + PV at half the square)",
               "rel_attn_fwd": "rel_fwd_mfma_kernel (skew relative flash forward; QK^T + QE^T + PV at half the square)",
               "rel_attn_bwd": "rel_bwd_dkv + rel_bwd_dq + rel_bwd_de + delta (6 products at half the square; 16 executed: "
                               "S, dP and Q.E^T are recomputed in each of the three kernels)",
               "alibi_attn_bwd": "attn_bwd_dkv_mfma_kernel + attn_bwd_dq_mfma_kernel + delta (5 products at half the square)",
-              "gemm_nt": "gemm_nt_kernel (MLP up-projection with bias + GELU + dropout epilogue)",
-              "gemm_tn": "gemm_tn_kernel + splitk_reduce_kernel (weight gradients, split-K fp32 slabs)"}
+              "gemm_nt": "gemm_nt_kernel (every x.W and dy.W^T projection of the blocks and the head: forward + dgrad, "
+                         "bias / residual / activation-backward epilogues)",
+              "gemm_tn": "gemm_tn_kernel + splitk_reduce_kernel (weight gradients of the blocks, split-K fp32 slabs)",
+              "gemm_tn_head": "gemm_tn_kernel + splitk_reduce_kernel (head weight gradient)",
+              "gemm_tn_embed": "gemm_tn_kernel + splitk_reduce_kernel (embedding gradient as a one-hot GEMM)"}
     lines = []
     for name, ev in events.items():
         if name not in labels or not ev:
@@ -235,14 +265,10 @@ def main():
         ach = fl / (tot_ms * 1e-3) / 1e12
         traffic = None
         if a.workload == "train_unified" and a.dtype == "bf16" and (B, S, H, dh) == (16, 2048, 8, 128):   # d=1024 ff=4096 fixed by the workload
-            traffic = pmc_traffic({
-                "alibi_attn_fwd": "attn_fwd_mfma_kernel<128,8> B16 S2048 H8",
-                "alibi_attn_bwd": "attn_bwd dkv+dq+delta <128> B16 S2048 H8 (per backward = per dkv launch)",
-                "gemm_tn": "gemm_tn_kernel + splitk_reduce, mean of dw2/dw1/dwp/dwqkv at T=32768 d=1024 ff=4096",
-                "gemm_nt": "gemm_nt_kernel<gelu,dropout> mlp1 T=32768 d=1024 ff=4096"}.get(name, ""))
+            traffic = pmc_traffic(name)
         lines.append({"bound": "mfma", "kernel": labels[name], "achieved": ach, "peak": PEAK_BF16_TFLOPS,
                       "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
-                      "traffic_unit": "HBM bytes per launch (TCC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic_pmc.json)",
+                      "traffic_unit": f"HBM bytes per launch (TCC FETCH_SIZE x2 + WRITE_SIZE, profiles/{TRAFFIC_FILE})",
                       "launches_timed": len(ev), "avg_launch_ms": tot_ms / len(ev), "flops_per_launch": fl / len(ev),
                       "ms_per_step": tot_ms / EVENT_STEPS})
     lines.sort(key=lambda r: -r["ms_per_step"])
@@ -258,6 +284,11 @@ def main():
         "roofline": roof,
         "roofline_other_kernels": lines[1:],
     }
+    if a.workload == "train_unified" and not a.no_decode:
+        # the other half of BASELINE.json's metric, in the same driver-visible record
+        del model, opt, ddp, batches
+        torch.cuda.empty_cache()
+        out["decode"] = bench_decode(a, device, rank, world, 64, 4096)
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
@@ -266,18 +297,19 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_decode(a, device, rank, world):
+def bench_decode(a, device, rank, world, B, new):
     """configs[3]: KV-cached greedy sampling, unified d=1024 L=6, batch 64/GPU, 4096-token continuation
-    (shortened by --seq for quick runs).  Reports generated tokens/s; HBM roofline on the decode kernel."""
+    (shortened by --seq for quick runs).  Returns the decode record: generated tokens/s (whole job), the step's
+    fraction of the HBM roofline (SURVEY 8(d) bytes: weights once + K/V rows of every layer at the mean context)
+    and the HBM roofline of the decode-attention kernel (HIP-event timed in a launch-by-launch pass)."""
     from musicgeneration_amd.model_baseline import build_everything_unified as cfg
     from musicgeneration_amd.decode import sample_next_plus_one
     from musicgeneration_amd import ops
-    B = a.batch or 64
-    new = a.seq or 4096
     L = 64 + new + 1
     args = cfg.m_args.get_copy()
     args.max_sequence = L
     args.dtype = a.dtype
+    torch.manual_seed(4321)
     model, _ = cfg.build_model_and_criterion(args)
     model = model.to(device).eval()
     g = torch.Generator(device=device).manual_seed(1234 + rank)
@@ -295,15 +327,15 @@ def bench_decode(a, device, rank, world):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    # second, untimed-for-`value` pass of the same continuation, launch by launch, with a HIP-event
+    # second, untimed-for-`value` pass over the head of the same continuation, launch by launch, with a HIP-event
     # pair around every decode-attention launch (a graph replay cannot be bracketed per kernel)
+    ev_new = min(new, 1024)
+    seq1 = seq0[:, :64 + ev_new + 1].clone()
     ops.KERNEL_EVENTS = {}
-    t1 = time.perf_counter()
-    seq1 = sample_next_plus_one(model, seq0, idx=64, deterministic=True, use_graph=False)
+    sample_next_plus_one(model, seq1, idx=64, deterministic=True, use_graph=False)
     torch.cuda.synchronize()
-    dt_eager = time.perf_counter() - t1
     events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
-    same = bool(torch.equal(seq1, seq))
+    same = bool(torch.equal(seq1[:, :-1], seq[:, :64 + ev_new]))
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -316,33 +348,28 @@ def bench_decode(a, device, rank, world):
     roof = None
     if ev:
         ms = sum(s.elapsed_time(e) for s, e, _ in ev) / len(ev)
-        mean_ctx = 64 + steps / 2
-        by = B * 2 * d * mean_ctx * esz                     # K and V rows of one layer, mean context
+        mean_ctx = 64 + (ev_new - 1) / 2
+        by = B * 2 * d * mean_ctx * esz                     # K and V rows of one layer, mean context of the timed launches
         ach = by / (ms * 1e-3) / 1e9
-        traffic = pmc_traffic("decode_attn_bf16_kernel B64 H8 dh128 R3 ctx2112") if (B, steps, a.dtype) == (64, 4096, "bf16") else None
-        roof = {"bound": "hbm", "kernel": "decode_attn_kernel", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": ach / PEAK_HBM_GBS, "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch at the mean context 2112 (TCC FETCH_SIZE x2 + WRITE_SIZE, "
-                                "profiles/r01_traffic_pmc.json)",
-                "launches_timed": len(ev), "avg_launch_ms": ms,
-                "bytes_per_launch": by, "timed_in": "launch-by-launch pass of the same continuation",
-                "launch_by_launch_tokens_per_s": B * steps / dt_eager, "graph_tokens_equal": same}
+        roof = {"bound": "hbm", "kernel": "decode_attn_bf16_kernel (append + attend, 3 query rows share every K/V load)",
+                "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                "traffic": pmc_traffic("decode_attn") if (B, a.dtype) == (64, "bf16") else None,
+                "traffic_unit": f"HBM bytes per launch at context 2112 (TCC FETCH_SIZE x2 + WRITE_SIZE, profiles/{TRAFFIC_FILE})",
+                "launches_timed": len(ev), "avg_launch_ms": ms, "bytes_per_launch": by,
+                "timed_in": f"launch-by-launch pass over the first {ev_new} steps of the same continuation (mean context "
+                            f"{mean_ctx:.0f})", "graph_tokens_equal": same}
     # whole-step HBM roofline of SURVEY 8(d): weights read once per step + the K/V rows of every layer at the mean context
     w_bytes = esz * (sum(p.numel() for l in model.decoder_layers for p in l.parameters()) + model.proj_class.weight.numel())
     step_bytes = w_bytes + B * 2 * Ln * d * (64 + steps / 2) * esz
     step_gbs = step_bytes / (dt / steps) / 1e9
-    out = {"metric": "decode tokens/sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": 16,
-           "step_bytes": step_bytes, "step_gb_per_s": step_gbs, "step_frac_of_hbm_peak": step_gbs / PEAK_HBM_GBS,
-           "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": a.dtype, "data": "synthetic primer, random-init weights",
-           "config": {"workload": f"decode_unified: alibi_unified d={d} L={Ln}, batch {B}/GPU, {steps}-token greedy "
-                                  f"continuation from a 63-token primer, KV cache", "global_batch": world * B,
-                      "seq_len": L, "parallelism": f"replicas{world}"},
-           "roofline": roof}
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    return {"metric": "decode tokens/sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": 16,
+            "step_bytes": step_bytes, "step_gb_per_s": step_gbs, "step_frac_of_hbm_peak": step_gbs / PEAK_HBM_GBS,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic primer, random-init weights",
+            "config": {"workload": f"decode_unified: alibi_unified d={d} L={Ln}, batch {B}/GPU, {steps}-token greedy "
+                                   f"continuation from a 63-token primer, KV cache", "global_batch": world * B,
+                       "seq_len": L, "parallelism": f"replicas{world}"},
+            "roofline": roof}
 
 
 if __name__ == "__main__":

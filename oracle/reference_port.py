@@ -150,9 +150,10 @@ def apply_rotary(t: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
 
 
 def decoder_block(sd: StateDict, pre: str, x: Tensor, mask: Tensor, n_heads: int,
-                  activation: str, rel_max_sequence: Optional[int] = None, rotary=None) -> Tensor:
-    """Post-LN block (dropout = identity).  alibi_unified.py:86-95 with
-    attention :56-67; relative variant relative_transformer.py:46-58,77-86."""
+                  activation: str, rel_max_sequence: Optional[int] = None, rotary=None, p_drop: float = 0.0) -> Tensor:
+    """Post-LN block.  alibi_unified.py:86-95 with attention :56-67; relative variant
+    relative_transformer.py:46-58,77-86.  p_drop > 0: training-mode dropout after the attention projection (:88) and
+    after the activation (:91), torch's CPU generator (parity tests run with p_drop = 0: RNG streams cannot match)."""
     d = x.shape[-1]
     c = conv1d(x, sd[pre + "attn.c_attn.w"], sd[pre + "attn.c_attn.b"])
     q, k, v = (_heads(t, n_heads) for t in torch.split(c, d, dim=2))
@@ -163,8 +164,12 @@ def decoder_block(sd: StateDict, pre: str, x: Tensor, mask: Tensor, n_heads: int
     else:
         a = relative_attention(q, k, v, sd[pre + "attn.E"], rel_max_sequence, mask)
     a = conv1d(_merge(a), sd[pre + "attn.c_proj.w"], sd[pre + "attn.c_proj.b"])
+    if p_drop > 0:
+        a = F.dropout(a, p_drop, training=True)
     x = F.layer_norm(a + x, (d,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"])
     h = _ACT[activation](F.linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"]))
+    if p_drop > 0:
+        h = F.dropout(h, p_drop, training=True)
     h = F.linear(h, sd[pre + "linear2.weight"], sd[pre + "linear2.bias"])
     return F.layer_norm(x + h, (d,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"])
 
@@ -173,20 +178,20 @@ def _n_layers(sd: StateDict) -> int:
     return 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("decoder_layers."))
 
 
-def _trunk(sd, h, mask, n_heads, activation, rel_max_sequence=None, rotary=None):
+def _trunk(sd, h, mask, n_heads, activation, rel_max_sequence=None, rotary=None, p_drop=0.0):
     for i in range(_n_layers(sd)):
-        h = decoder_block(sd, f"decoder_layers.{i}.", h, mask, n_heads, activation, rel_max_sequence, rotary)
+        h = decoder_block(sd, f"decoder_layers.{i}.", h, mask, n_heads, activation, rel_max_sequence, rotary, p_drop)
     return final_norm(h, sd["norm.g"], sd["norm.b"])
 
 
 # --------------------------------------------------------------------------
 # models
 # --------------------------------------------------------------------------
-def unified_forward(sd: StateDict, x: Tensor, n_heads: int, activation: str = "gelu") -> Tensor:
+def unified_forward(sd: StateDict, x: Tensor, n_heads: int, activation: str = "gelu", p_drop: float = 0.0) -> Tensor:
     """alibi_unified.py:124-138.  x:[B,S] int -> logits [B,S,V]."""
     S = x.shape[1]
     h = F.embedding(x.long(), sd["embed.weight"])
-    h = _trunk(sd, h, alibi_mask(S, n_heads), n_heads, activation)
+    h = _trunk(sd, h, alibi_mask(S, n_heads), n_heads, activation, p_drop=p_drop)
     return F.linear(h, sd["proj_class.weight"], sd["proj_class.bias"])
 
 
@@ -327,9 +332,9 @@ def make_trainable(sd: StateDict) -> StateDict:
 
 
 def unified_train_step(sd: StateDict, opt: torch.optim.Optimizer, x: Tensor, y: Tensor,
-                       n_heads: int, pad_index: int = 1, activation: str = "gelu") -> float:
+                       n_heads: int, pad_index: int = 1, activation: str = "gelu", p_drop: float = 0.0) -> float:
     """forward, CE, zero_grad, backward, optimizer.step; returns the loss."""
-    logits = unified_forward(sd, x, n_heads, activation)
+    logits = unified_forward(sd, x, n_heads, activation, p_drop)
     loss, _ = unified_criterion(logits, y, pad_index)
     assert not torch.isnan(loss).any()
     opt.zero_grad()

@@ -577,7 +577,7 @@ def test_bench_data_parallel_path_on_rccl():
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--seq", "512",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--no-decode"]
     lines = []
     for extra in ([], ["--force-dp"], ["--force-dp", "--dp-mode", "inplace"]):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
