@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import ops, torch_ops  # noqa: F401  (torch_ops registers torch.ops.mgx.*)
 from ..base_layers import Attention, BlockWeights, Conv1d, Norm, ShadowCache, active_dtype, resolve_dtype, \
     generate_square_subsequent_mask
 from ..metrics import SamplewiseAccuracy
@@ -69,22 +69,8 @@ class SimpleAttention(Attention):
         """Stand-alone use (the block fuses this path).  `mask` is ignored: the
         kernel applies the ALiBi + causal bias itself."""
         qkv = self.c_attn(x)
-        a = _AttnOnly.apply(qkv.contiguous(), self.slopes, self.heads)
+        a = torch.ops.mgx.alibi_attention(qkv.contiguous(), self.slopes, self.heads)[0]     # torch_ops.py
         return self.c_proj(a)
-
-
-class _AttnOnly(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, qkv, slopes, heads):
-        out, lse = ops.alibi_attn_fwd(qkv, slopes, heads)
-        ctx.save_for_backward(qkv, out, lse, slopes)
-        ctx.heads = heads
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        qkv, out, lse, slopes = ctx.saved_tensors
-        return ops.alibi_attn_bwd(dout.contiguous(), qkv, out, lse, slopes, ctx.heads), None, None
 
 
 class DecoderBlock(nn.Module):

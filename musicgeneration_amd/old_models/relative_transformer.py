@@ -11,26 +11,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import ops, torch_ops  # noqa: F401  (torch_ops registers torch.ops.mgx.*)
 from ..base_layers import Attention, BlockWeights, Conv1d, Norm, ShadowCache, active_dtype, resolve_dtype, \
     tied_embed, tied_head, \
     generate_square_subsequent_mask
 from ..model_baseline.alibi_unified import _activation_name
-
-
-class _RelAttnOnly(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, qkv, E_master, E, heads):
-        out, lse = ops.rel_attn_fwd(qkv, E, heads)
-        ctx.save_for_backward(qkv, out, lse, E)
-        ctx.heads = heads
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        qkv, out, lse, E = ctx.saved_tensors
-        dqkv, dE = ops.rel_attn_bwd(dout.contiguous(), qkv, out, lse, E, ctx.heads)
-        return dqkv, dE, None, None
 
 
 class RelativeAttention(Attention):
@@ -45,7 +30,7 @@ class RelativeAttention(Attention):
     def forward(self, x, mask=None):
         """Stand-alone path; `mask` ignored (causal inside the kernel)."""
         qkv = self.c_attn(x)
-        a = _RelAttnOnly.apply(qkv.contiguous(), self.E, self.E.detach().to(qkv.dtype), self.heads)
+        a = torch.ops.mgx.rel_attention(qkv.contiguous(), self.E.to(qkv.dtype), self.heads)[0]    # torch_ops.py
         return self.c_proj(a)
 
 

@@ -590,28 +590,6 @@ def padded_head(h, w_pad, w_pad_t, b_pad, masters):
 
 
 # ---------------------------------------------------------------------------
-# final Norm (base_layers.py:36-41) as an autograd op
-# ---------------------------------------------------------------------------
-class _LayerNorm(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
-        xc = x.contiguous()
-        y, z, mean, rstd = ln_residual_fwd(xc, None, gamma, beta, eps)
-        ctx.save_for_backward(z, mean, rstd, gamma)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        z, mean, rstd, gamma = ctx.saved_tensors
-        dz, _, dg, db = ln_residual_bwd(dy.contiguous(), None, z, mean, rstd, gamma)
-        return dz, dg, db, None
-
-
-def layer_norm(x, gamma, beta, eps=1e-5):
-    return _LayerNorm.apply(x, gamma, beta, eps)
-
-
-# ---------------------------------------------------------------------------
 # whole post-LN decoder block as one autograd node
 # ---------------------------------------------------------------------------
 def _mfma_gemms(x2, d, ff):

@@ -764,3 +764,40 @@ def test_softmax_xent_multi_equals_three_single_heads():
         assert float(u) == float(v)
     assert torch.equal(a.grad, b.grad)
     assert float(a.grad[:, 425:].abs().max()) == 0.0
+
+
+def test_torch_library_ops_registered_and_consistent():
+    """torch.ops.mgx.* (musicgeneration_amd/torch_ops.py): schema + fake kernel + autograd registration pass
+    torch.library.opcheck, and the differentiable operators give the wrappers' results and gradients."""
+    from musicgeneration_amd import torch_ops  # noqa: F401
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    B, S, H, dh = 2, 96, 2, 64
+    qkv = torch.randn(B, S, 3 * H * dh, generator=g).bfloat16().cuda().requires_grad_(True)
+    slopes = torch.tensor(O.alibi_slopes(H), dtype=torch.float32).cuda()
+    out, lse = torch.ops.mgx.alibi_attention(qkv, slopes, H)
+    ref, ref_lse = ops.alibi_attn_fwd(qkv.detach(), slopes, H)
+    assert torch.equal(out, ref) and torch.equal(lse, ref_lse)
+    dout = torch.randn(B, S, H * dh, generator=g).bfloat16().cuda()
+    out.backward(dout)
+    assert torch.equal(qkv.grad, ops.alibi_attn_bwd(dout, qkv.detach(), ref, ref_lse, slopes, H))
+    torch.library.opcheck(torch.ops.mgx.alibi_attention.default, (qkv.detach().requires_grad_(True), slopes, H),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    x = torch.randn(40, 256, generator=g).cuda().requires_grad_(True)
+    gam, bet = torch.rand(256, generator=g).cuda().requires_grad_(True), torch.rand(256, generator=g).cuda().requires_grad_(True)
+    torch.library.opcheck(torch.ops.mgx.layer_norm_fwd.default, (x, gam, bet, 1e-5),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    y = torch_ops.layer_norm(x, gam, bet)
+    want = torch.nn.functional.layer_norm(x.detach(), (256,), gam.detach(), bet.detach())
+    assert gu.rel_err(y, want) < F32_TOL
+    a = torch.randn(130, 128, generator=g).bfloat16().cuda().requires_grad_(True)
+    bt = (torch.randn(72, 128, generator=g) / 11).bfloat16().cuda().requires_grad_(True)
+    bias = torch.randn(72, generator=g).cuda().requires_grad_(True)
+    c = torch.ops.mgx.gemm_nt(a, bt, bias)
+    want = a.detach().float() @ bt.detach().float().t() + bias.detach()
+    assert gu.rel_err(c.float(), want) < BF16_TOL
+    dc = torch.randn(130, 72, generator=g).bfloat16().cuda()
+    c.backward(dc)
+    assert gu.rel_err(a.grad.float(), dc.float() @ bt.detach().float()) < BF16_TOL
+    assert gu.rel_err(bt.grad.float(), dc.float().t() @ a.detach().float()) < BF16_TOL
+    assert gu.rel_err(bias.grad, dc.float().sum(0)) < 1e-4
