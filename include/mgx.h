@@ -55,9 +55,12 @@ int mgx_alibi_attn_fwd(const void* qkv, const float* slopes, void* out, float* l
                        int B, int S, int H, int dh, int dtype, void* stream);
 
 /* Backward of the above.  dqkv [B,S,3,H,dh] receives dq | dk | dv (fully
- * overwritten).  delta [B,H,S] fp32 is caller-provided scratch (rowsum(dout*out)). */
+ * overwritten).  workspace: caller-provided fp32 scratch of
+ * mgx_alibi_attn_bwd_workspace_floats(B, S, H) elements (row statistics: rowsum(dout*out) and the
+ * shifted normaliser, rows padded to a multiple of 64). */
+long mgx_alibi_attn_bwd_workspace_floats(int B, int S, int H);
 int mgx_alibi_attn_bwd(const void* dout, const void* qkv, const void* out, const float* lse,
-                       const float* slopes, void* dqkv, float* delta,
+                       const float* slopes, void* dqkv, float* workspace,
                        int B, int S, int H, int dh, int dtype, void* stream);
 
 /* ---- skew relative-position causal attention --------------------------------

@@ -23,6 +23,7 @@ PROTOTYPES = {
     "mgx_version": (C.c_int, []),
     "mgx_last_error_string": (C.c_char_p, []),
     "mgx_alibi_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mgx_alibi_attn_bwd_workspace_floats": (_l, [_i, _i, _i]),
     "mgx_alibi_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mgx_rel_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mgx_rel_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -46,6 +46,10 @@ extern "C" int mgx_alibi_attn_fwd(const void* qkv, const float* slopes, void* ou
     return mgx_attn_fwd_generic(0, qkv, slopes, nullptr, out, lse, B, S, H, dh, 0, dtype, (hipStream_t)stream);
 }
 
+extern "C" long mgx_alibi_attn_bwd_workspace_floats(int B, int S, int H) {
+    return 2L * B * H * ((S + 63) / 64 * 64);
+}
+
 extern "C" int mgx_alibi_attn_bwd(const void* dout, const void* qkv, const void* out, const float* lse,
                                   const float* slopes, void* dqkv, float* delta, int B, int S, int H, int dh,
                                   int dtype, void* stream) {

@@ -20,6 +20,10 @@
 #include <type_traits>
 #include "attn_mfma_common.h"
 
+// attn_bwd_pipe.hip
+int mgx_attn_bwd_dkv_pipe(const void* dout, const void* qkv, const void* out, const float* lse, const float* slopes,
+                          void* dqkv, float* stats, int B, int S, int H, int dh, hipStream_t st);
+
 namespace {
 
 // ===========================================================================
@@ -194,8 +198,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_mfma_kernel(const bf16_t*
 template <int DH, int NW>
 __global__ __launch_bounds__(64 * NW, MGX_DQ_OCC) void attn_bwd_dq_mfma_kernel(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
-    const float* __restrict__ delta, const float* __restrict__ slopes, bf16_t* __restrict__ dqkv, int S, int H,
-    float c, float scale) {
+    const float* __restrict__ nd /* -delta, rows padded to Sp */, const float* __restrict__ slopes,
+    bf16_t* __restrict__ dqkv, int S, int Sp, int H, float c, float scale) {
     constexpr int NT = 64 * NW, QB = 32 * NW, TB = Img<DH>::TILE_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[4 * TB];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(64 * NW, MGX_DQ_OCC) void attn_bwd_dq_mfma_kernel(
         gf[ks] = qok ? *reinterpret_cast<const bf16x8*>(gp + (long)qi * H * DH + ks * 16 + 8 * h5) : z;
     }
     const float lse2 = qok ? lse[((long)b * H + h) * S + qi] * LOG2E : INFINITY;
-    const float ndelta = qok ? -delta[((long)b * H + h) * S + qi] : 0.f;
+    const float ndelta = qok ? nd[((long)b * H + h) * Sp + qi] : 0.f;
     const float sb = slopes[h] * LOG2E / c;
 
     f32x16 dq[DH / 32];
@@ -466,21 +470,17 @@ __global__ __launch_bounds__(64 * NW, MGX_DKV_OCC) void attn_bwd_dkv_mfma_kernel
 
 template <int DH, int NW>
 int launch_bwd_mfma(const void* dout, const void* qkv, const void* out, const float* lse, const float* slopes,
-                    void* dqkv, float* delta, int B, int S, int H, hipStream_t st) {
+                    void* dqkv, float* ws, int B, int S, int H, hipStream_t st) {
     const float scale = 1.0f / sqrtf((float)DH);
     const float c = LOG2E * scale;
-    const long n_chunks = (long)B * S * H * (DH / 8);
-    hipLaunchKernelGGL((attn_delta_mfma_kernel<DH>), dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st,
-                       (const bf16_t*)dout, (const bf16_t*)out, delta, n_chunks, S, H);
-    MGX_CHECK_LAUNCH("attn_delta_mfma");
-    constexpr int NWK = MGX_DKV_NW;
-    dim3 gridk(H, B, (S + 32 * NWK - 1) / (32 * NWK));
-    hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<DH, NWK>), gridk, dim3(64 * NWK), 0, st, (const bf16_t*)dout,
-                       (const bf16_t*)qkv, lse, delta, slopes, (bf16_t*)dqkv, S, H, c, scale);
-    MGX_CHECK_LAUNCH("attn_bwd_dkv_mfma");
+    const int Sp = (S + 63) / 64 * 64;
+    // statistics pre-pass (nl | nd in ws) + the software-pipelined dK/dV kernel (attn_bwd_pipe.hip)
+    const int rc = mgx_attn_bwd_dkv_pipe(dout, qkv, out, lse, slopes, dqkv, ws, B, S, H, DH, st);
+    if (rc != MGX_OK) return rc;
+    const float* nd = ws + (long)B * H * Sp;
     dim3 grid(H, B, (S + 32 * NW - 1) / (32 * NW));
     hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DH, NW>), grid, dim3(64 * NW), 0, st, (const bf16_t*)dout, (const bf16_t*)qkv,
-                       lse, delta, slopes, (bf16_t*)dqkv, S, H, c, scale);
+                       lse, nd, slopes, (bf16_t*)dqkv, S, Sp, H, c, scale);
     MGX_CHECK_LAUNCH("attn_bwd_dq_mfma");
     return MGX_OK;
 }

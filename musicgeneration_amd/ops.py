@@ -105,7 +105,7 @@ def alibi_attn_bwd(dout, qkv, out, lse, slopes, n_heads: int, generic: bool = Fa
     if dout.shape != out.shape or out.shape != (B, S, d):
         raise ValueError("bad attention backward shapes")
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty_like(lse)
+    delta = torch.empty(int(lib.mgx_alibi_attn_bwd_workspace_floats(B, S, n_heads)), dtype=torch.float32, device=qkv.device)
     with _timed("alibi_attn_bwd", 5.0 * B * n_heads * S * S * (d // n_heads)):      # 5 products at half the square
         check(lib.mgx_alibi_attn_bwd(_p(dout), _p(qkv), _p(out), _p(lse), _p(slopes), _p(dqkv), _p(delta), B, S, n_heads,
                                      d // n_heads, _attn_dt(qkv, generic), _stream()), "mgx_alibi_attn_bwd")
