@@ -46,8 +46,9 @@ extern "C" int mgx_alibi_attn_fwd(const void* qkv, const float* slopes, void* ou
     return mgx_attn_fwd_generic(0, qkv, slopes, nullptr, out, lse, B, S, H, dh, 0, dtype, (hipStream_t)stream);
 }
 
+long mgx_attn_bwd_pipe_stats_floats(int B, int S, int H);     // attn_bwd_pipe.hip
 extern "C" long mgx_alibi_attn_bwd_workspace_floats(int B, int S, int H) {
-    return 2L * B * H * ((S + 63) / 64 * 64);
+    return mgx_attn_bwd_pipe_stats_floats(B, S, H);
 }
 
 extern "C" int mgx_alibi_attn_bwd(const void* dout, const void* qkv, const void* out, const float* lse,

@@ -2,23 +2,23 @@
 // Autograd of SimpleAttention.multihead_attn (model_baseline/alibi_unified.py:40-54).
 //
 // dK/dV kernel.  One wave per SIMD (4 waves, 32 keys each; K and V fragments and the 32 x dh dK / dV accumulators
-// stay in registers); queries arrive in UNITS of 32 rows (Q and dO, 32 x dh each) through a ring of NB LDS slots
-// filled by LDS-DMA.  Per unit u and wave:
-//     A(u)  S = Q.K^T, dP = dO.V^T                          2*dh/16 MFMAs
-//     B(u)  P = exp2(c S + bias - lse), dS = P*(dP - delta)  VALU (packed fp32), bf16 packs
-//     C(u)  dV^T += dO^T.P, dK^T += Q^T.dS                  4*dh/32 MFMAs   (P, dS straight from the accumulators)
-// and the loop body issues  X(u) = A(u+1) interleaved with B(u)  then  Y(u) = C(u) interleaved with the LDS reads
-// of the next stages, so the MFMA pipe always has independent work while the VALU, the LDS and the DMA engine run
-// beside it.  All LDS reads are inline asm with explicit s_waitcnt (hipcc would otherwise drain vmcnt before every
-// read that follows an LDS-DMA).
+// stay in registers).  A workgroup is PERSISTENT: it walks a list of (batch, head, 128-key block) items, heavy and
+// light key blocks paired so that every workgroup gets the same number of query rows, and the LDS-DMA stream of
+// query tiles (64 rows of Q and dO + their row statistics, ring of 4 slots) runs on across item boundaries.
+// Queries are consumed in UNITS of 32 rows.  Per unit u and wave:
+//     A(u)  S = Q.K^T + nl, dP = dO.V^T + nd       2*(dh/16 + 1) MFMAs; the row statistics enter as one extra k-step
+//                                                   (A = the statistic split into three bf16, B = ones), so no
+//                                                   per-row value has to be fetched into registers for the VALU
+//     B(u)  P = exp2(c S + bias), dS = P * dP       plain fp32 VALU (v_pk_* does not run beside the MFMA pipe)
+//     C(u)  dV^T += dO^T.P, dK^T += Q^T.dS          4*dh/32 MFMAs   (P, dS straight from the accumulators)
+// and the loop body issues  X(u) = A(u+1) with the exponentials of B(u) between the MFMAs, then  Y(u) = C(u) with
+// the dS half of B(u) between them; every gap between two MFMAs also carries ONE KiB of LDS fragment reads for a
+// later stage (more than that per gap does not hide under an MFMA: tools/mfma_overlap_lab2.cpp).
+// All LDS reads are inline asm with explicit s_waitcnt (hipcc would otherwise drain vmcnt before every read that
+// follows an LDS-DMA).
 #include <type_traits>
 #include <utility>
 #include "attn_mfma_common.h"
-
-// No packed-fp32 VALU in this file: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do not run beside the MFMA pipe
-// (tools/mfma_overlap_lab.cpp: two of them per MFMA cost as much as ten plain VALU instructions), and hipcc forms
-// them from any pair of scalar operations.
-#pragma clang attribute push(__attribute__((target("no-packed-fp32-ops"))), apply_to = function)
 
 namespace {
 
@@ -33,12 +33,9 @@ __device__ __forceinline__ bf16x8 lds_b128(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
     return r;
 }
-template <int OFF>
-__device__ __forceinline__ f32x4 lds_f128(unsigned addr) {
-    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
-    f32x4 r;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
-    return r;
+
+__device__ __forceinline__ void lds_write_b64(unsigned addr, const bf16x4& v) {
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
 // ---- AGPRs are allocated BY HAND.  hipcc keeps every MFMA accumulator of a 1-wave-per-SIMD kernel in AGPRs and copies
@@ -46,7 +43,8 @@ __device__ __forceinline__ f32x4 lds_f128(unsigned addr) {
 // VGPRs as well; so everything that lives in the AGPR half of the register file (dK / dV accumulators, the K / V
 // fragments, the transposed Q / dO fragments) is named literally in the asm text (register numbers are template
 // constants printed through "n" operands) and never exists as a compiler value.  The compiler owns the VGPR half
-// (a kernel of this shape needs < 256 of them, so it has no reason to spill into AGPRs; the build checks the ISA).
+// (a kernel of this shape needs < 256 of them, so it has no reason to spill into AGPRs; check the ISA after a change:
+// no v_accvgpr_* outside the item prologue / epilogue).
 // Its hazard recogniser does not see these MFMAs: the pipeline keeps every VALU producer / consumer of an MFMA
 // operand a whole stage away, and explicit s_nop's guard the places where that is not so.
 template <int R0, int OFF0, int OFF1>
@@ -63,26 +61,18 @@ __device__ __forceinline__ void mfma_s0(f32x16& d, const bf16x8& a) {
 }
 template <int RB>
 __device__ __forceinline__ void mfma_s(f32x16& d, const bf16x8& a) {
-#ifndef PIPE_ABL_NOMFMA
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0" : "+v"(d) : "v"(a), "n"(RB), "n"(RB + 3));
-#endif
-#ifdef PIPE_ABL_MFMA2
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0" : "+v"(d) : "v"(a), "n"(RB), "n"(RB + 3));
-#endif
+}
+// the statistics step: B (ones in k = 0..2) in VGPRs
+__device__ __forceinline__ void mfma_sv(f32x16& d, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
 }
 // dV / dK: a[RD..RD+15] += A (transposed fragment, a[RA..RA+3]) x B (P or dS, VGPRs)
 template <int RD, int RA>
 __device__ __forceinline__ void mfma_acc(const bf16x8& b) {
-#ifndef PIPE_ABL_NOMFMA
     asm volatile("v_mfma_f32_32x32x16_bf16 a[%1:%2], a[%3:%4], %0, a[%1:%2]"
                  :
                  : "v"(b), "n"(RD), "n"(RD + 15), "n"(RA), "n"(RA + 3));
-#endif
-#ifdef PIPE_ABL_MFMA2
-    asm volatile("v_mfma_f32_32x32x16_bf16 a[%1:%2], a[%3:%4], %0, a[%1:%2]"
-                 :
-                 : "v"(b), "n"(RD), "n"(RD + 15), "n"(RA), "n"(RA + 3));
-#endif
 }
 template <int R>
 __device__ __forceinline__ void agpr_zero() {
@@ -97,6 +87,17 @@ __device__ __forceinline__ float agpr_get() {
 template <int R0>
 __device__ __forceinline__ void global_b128_to_agpr(const void* p) {
     asm volatile("global_load_dwordx4 a[%1:%2], %0, off" ::"v"(p), "n"(R0), "n"(R0 + 3) : "memory");
+}
+// fp32 VALU the compiler may not pair into v_pk_fma_f32 / v_pk_mul_f32 (those do not run beside the MFMA pipe)
+__device__ __forceinline__ float fma_np(float a, float b, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float mul_np(float a, float b) {
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 template <int... I, typename F>
@@ -119,16 +120,27 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     return r.u;
 }
 
-// nl[b,h,i] = -(slope_h * (i mod 32) + lse) * log2e      (log2 units, relative to the start of the 32-row unit),
-//             -inf for S <= i < Sp
-// nd[b,h,i] = -sum_d dout*out                               0 for S <= i < Sp
+// Row statistics for the backward, rows padded to Sp (a multiple of 64):
+//   nla[b,h,i] (16 B) = -(slope_h * (i mod 32) + lse) * log2e / c  split into three bf16 (hi, mid, lo) + five zeros:
+//                       the initial value of S in raw-score units, relative to the start of the 32-row unit;
+//                       -1e30 for S <= i < Sp (P becomes exactly 0)
+//   nda[b,h,i] (16 B) = -sum_d dout*out, split the same way; 0 for the padding rows
+//   nd32[b,h,i]       = the same value in fp32 (dQ kernel)
+__device__ __forceinline__ void split3(float x, bf16_t* dst) {
+    const bf16_t hi = (bf16_t)x;
+    const float r1 = x - (float)hi;
+    const bf16_t mid = (bf16_t)r1;
+    const bf16_t lo = (bf16_t)(r1 - (float)mid);
+    bf16x8 v = {hi, mid, lo, 0, 0, 0, 0, 0};
+    *reinterpret_cast<bf16x8*>(dst) = v;
+}
 template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const bf16_t* __restrict__ dout,
                                                               const bf16_t* __restrict__ out,
                                                               const float* __restrict__ lse,
-                                                              const float* __restrict__ slopes, float* __restrict__ nl,
-                                                              float* __restrict__ nd, long n_chunks, int S, int Sp,
-                                                              int H) {
+                                                              const float* __restrict__ slopes, bf16_t* __restrict__ nla,
+                                                              bf16_t* __restrict__ nda, float* __restrict__ nd32,
+                                                              long n_chunks, int S, int Sp, int H, float inv_c) {
     constexpr int LPH = DH / 8;
     const long ch = (long)blockIdx.x * 256 + threadIdx.x;      // chunk of the padded [B, Sp, H, dh/8] index space
     const long bh = ch / LPH;                                  // (b*Sp + i)*H + h
@@ -149,354 +161,511 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const bf16_t* __res
     for (int o = 1; o < LPH; o <<= 1) s += __shfl_xor(s, o, 64);
     if (ch < n_chunks && (ch % LPH) == 0) {
         const long dst = (b * H + h) * Sp + i;
-        if (i < S) {
-            nl[dst] = -(slopes[h] * (float)(i & 31) + lse[(b * H + h) * S + i]) * LOG2E;
-            nd[dst] = -s;
-        } else {
-            nl[dst] = -INFINITY;
-            nd[dst] = 0.f;
-        }
+        const float xl = i < S ? -(slopes[h] * (float)(i & 31) + lse[(b * H + h) * S + i]) * LOG2E * inv_c : -1e30f;
+        const float xd = i < S ? -s : 0.f;
+        split3(xl, nla + dst * 8);
+        split3(xd, nda + dst * 8);
+        nd32[dst] = xd;
     }
 }
 
 template <int DH>
 struct DkvCfg {
-    static constexpr int NB = 7;                       // LDS ring slots (one 32-query unit each)
-    static constexpr int UB = 32 * DH * 2;             // bytes of one 32 x dh bf16 image
-    static constexpr int SLOT = 2 * UB + 1024;         // Q image, dO image, 4 per-wave copies of (nl[32], nd[32])
-    static constexpr int VM_PER_UNIT = 2 * (DH / 64) + 1;   // LDS-DMA instructions per wave and unit
+    static constexpr int NB = 4;                       // LDS ring slots (one 64-query tile each)
+    static constexpr int UB = 32 * DH * 2;             // bytes of one 32 x dh bf16 image (a unit)
+    static constexpr int TB = 2 * UB;                  // a 64-row tile of Q or dO
+    static constexpr int AUG = 2 * TB;                 // offset of the statistics: nla[64] then nda[64], 16 B per row
+    static constexpr int SLOT = 2 * TB + 2048;
+    static constexpr int VM_PER_TILE = 4 * (DH / 64) + 1;   // LDS-DMA instructions per wave and tile
     static constexpr int KS = DH / 16, DB = DH / 32;
-    static constexpr int NG_X = 2 * KS;                // MFMAs of stage A
+    static constexpr int NG_X = 2 * KS + 2;            // MFMAs of stage A (S and dP chains, statistics step last)
     static constexpr int NG_Y = 4 * DB;                // MFMAs of stage C: NG_Y / 2 for dV, then NG_Y / 2 for dK
     static constexpr int HF = NG_Y / 2;
+    static constexpr int EPG = DH == 128 ? 1 : 2;      // elements of P per gap of X
     // AGPR map
-    static constexpr int R_DK = 0, R_DV = 16 * DB, R_KF = 32 * DB, R_VF = R_KF + 4 * KS, R_TR = R_VF + 4 * KS;
-    static constexpr int R_END = R_TR + 4 * NG_Y;      // 256 at dh 128, 128 at dh 64
-    // LDS reads issued in gap g of Y (first half only): two ds_read_b64_tr_b16 + 8 / HF statistics reads
-    static constexpr int SPG = 8 / HF;                 // 1 at dh 128, 2 at dh 64
-    static constexpr int reads_in_gap(int g) { return g < HF ? 2 + SPG : 0; }
-    // reads issued after those of gap f - HF and before MFMA f: what lgkmcnt may still show
-    static constexpr int y_wait(int f) {
-        int n = 0;
-        for (int g = f - HF + 1; g < f; ++g) n += reads_in_gap(g);
-        return n < 12 ? n : 12;
-    }
+    static constexpr int R_DK = 0, R_DV = 16 * DB, R_KF = 32 * DB, R_VF = R_KF + 4 * KS, R_TV = R_VF + 4 * KS;
+    static constexpr int R_TK = R_TV + 4 * HF, R_END = R_TK + 4 * HF;   // 256 at dh 128, 128 at dh 64
+};
+
+struct DkvArgs {
+    const bf16_t* dout;
+    const bf16_t* qkv;
+    const bf16_t* nla;
+    const bf16_t* nda;
+    const float* slopes;
+    bf16_t* dqkv;
+    int B, S, Sp, H;
+    float c, scale;
+    int nkb, np;        // 128-key blocks per (b,h); pairs of them
+    int nwork;          // B*H*np pairs in all
 };
 
 template <int DH>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pipe_kernel(
-    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qkv, const float* __restrict__ nl,
-    const float* __restrict__ nd, const float* __restrict__ slopes, bf16_t* __restrict__ dqkv, int S, int Sp, int H,
-    float c, float scale) {
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pipe_kernel(DkvArgs g) {
     using Cfg = DkvCfg<DH>;
-    constexpr int NB = Cfg::NB, UB = Cfg::UB, SLOT = Cfg::SLOT, G8 = Img<DH>::G8;
-    constexpr int KS = Cfg::KS, DB = Cfg::DB, HF = Cfg::HF;
+    constexpr int NB = Cfg::NB, UB = Cfg::UB, TB = Cfg::TB, SLOT = Cfg::SLOT, G8 = Img<DH>::G8;
+    constexpr int KS = Cfg::KS, DB = Cfg::DB, HF = Cfg::HF, NGX = Cfg::NG_X, VM = Cfg::VM_PER_TILE;
     static_assert(Cfg::R_END <= 256, "AGPR map");
-    __shared__ __attribute__((aligned(1024))) char smem[NB * SLOT];
+    static_assert(2 * VM <= NGX, "one LDS-DMA piece per odd gap of X");
+    constexpr int EPI = NB * SLOT;                       // 4 KiB per wave: transposition buffer of the item epilogue
+    __shared__ __attribute__((aligned(1024))) char smem[NB * SLOT + 4 * 4096];
     // the AGPRs named in the asm below, made known to the compiler's resource accounting (it allocates none itself)
     asm volatile("" ::: "a0", "a127", "a255");
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h5 = lane >> 5;
-    const int jb0 = blockIdx.z * 128, jw0 = jb0 + 32 * w;        // early key blocks (most queries) first
-    const int b = blockIdx.y, h = blockIdx.x;
+    const int S = g.S, Sp = g.Sp, H = g.H;
     const unsigned rs = 3u * H * DH;
-    const bf16_t* base = qkv + (long)b * S * rs + (long)h * DH;
-    const bf16_t* kp = base + (long)H * DH;
-    const bf16_t* vp = base + 2L * H * DH;
-    const bf16_t* gp = dout + (long)b * S * H * DH + (long)h * DH;
-    const float* nl_bh = nl + ((long)b * H + h) * Sp;
-    const float* nd_bh = nd + ((long)b * H + h) * Sp;
+    const unsigned rs2 = rs * 2u, gs2 = (unsigned)(H * DH * 2);
     const LaneAddr<DH> la(lane);
+    const int tend = Sp / 64;                            // tiles of an item: [2 kb, tend)
+    const int tlast_real = (S - 1) / 64;                 // last tile that holds real rows
 
-    const int j = jw0 + l31;
-    const bool jok = j < S;
-    {
+    // ---- this workgroup's items.  Work pair q = (b*H + h, p) -> key blocks p (heavy) and nkb-1-p (light); the
+    // workgroups of one XCD (blockIdx % 8) take consecutive pairs, i.e. the key blocks of the same few (b, h), so
+    // that one Q / dO stream serves them from that XCD's L2.
+    const int G = gridDim.x;
+    const int gq = (G & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
+    const int nseq = 2 * ((g.nwork + G - 1) / G);        // sequence numbers [0, nseq)
+    auto item_at = [&](int n, int& bh, int& kb) -> bool {
+        const int q = (n >> 1) * G + gq;
+        if (n >= nseq || q >= g.nwork) return false;
+        bh = q / g.np;
+        const int p = q - bh * g.np;
+        kb = (n & 1) ? g.nkb - 1 - p : p;
+        return !(n & 1) || kb > p;
+    };
+    auto next_item = [&](int n, int& bh, int& kb) -> int {   // first valid sequence number > n, or nseq
+        for (++n; n < nseq; ++n)
+            if (item_at(n, bh, kb)) return n;
+        return nseq;
+    };
+
+    // ---- producer: LDS-DMA of one 64-row tile.  Wave w brings rows 16w..16w+15 of Q and of dO (two 8-row groups of
+    // DH/64 KiB-pieces each) and one KiB of statistics (even waves nla, odd waves nda; written twice, same bytes).
+    // Lane l of a piece lands at byte 16 l: 512-B sub-tile l >> 5, row (l >> 2) & 7, slot l & 3 of the image
+    //   off(row, ch) = G8 (row >> 3) + 512 (ch >> 2) + 64 (row & 7) + 16 ((ch & 3) ^ ((row >> 2) & 3)).
+    const int rowin = (lane >> 2) & 7;
+    unsigned offq[2][DH / 64], offg[2][DH / 64];         // per-lane byte offsets from the tile's first row
+    int prow[2];
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+        prow[gi] = 16 * w + 8 * gi + rowin;
+        const int sx = (lane & 3) ^ ((prow[gi] >> 2) & 3);
+#pragma unroll
+        for (int hf = 0; hf < DH / 64; ++hf) {
+            const unsigned colb = (unsigned)((4 * (2 * hf + (lane >> 5)) + sx) * 16);
+            offq[gi][hf] = (unsigned)prow[gi] * rs2 + colb;
+            offg[gi][hf] = (unsigned)prow[gi] * gs2 + colb;
+        }
+    }
+    int p_n, p_bh = 0, p_kb = 0, p_tile = 0;             // producer cursor: item sequence number, tile inside it
+    int p_slot = 0;
+    const char* p_q = nullptr;                           // Q rows, dO rows, statistics of the producer's (b, h)
+    const char* p_g = nullptr;
+    const char* p_a = nullptr;
+    auto producer_set_item = [&]() {
+        const int b = p_bh / H, h = p_bh - b * H;
+        p_q = (const char*)(g.qkv + (long)b * S * rs + (long)h * DH);
+        p_g = (const char*)(g.dout + (long)b * S * H * DH + (long)h * DH);
+        p_a = (const char*)(((w & 1) ? g.nda : g.nla) + ((long)b * H + h) * Sp * 8) + 16 * lane;
+        p_tile = 2 * p_kb;
+    };
+    // One tile = VM pieces per wave.  produce_begin fixes the source / destination of the tile at the cursor,
+    // produce_piece<k> issues one LDS-DMA instruction, produce_end advances the cursor.  The pieces are issued one
+    // per MFMA gap: nine of them back to back stall the wave for ~600 cycles (the four waves' 36 KiB-instructions
+    // queue up behind one texture-address unit).
+    const char* p_q0 = nullptr;
+    const char* p_g0 = nullptr;
+    int p_back[2] = {0, 0};
+    auto produce_begin = [&]() {
+        const int tq = min(p_tile, tlast_real);          // padding tiles re-read real rows (their P is exactly 0)
+        p_q0 = p_q + (long)tq * 64 * rs2;
+        p_g0 = p_g + (long)tq * 64 * gs2;
+        // rows past the end re-read row S-1
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) p_back[gi] = max(tq * 64 + prow[gi] - (S - 1), 0);
+    };
+    auto produce_piece = [&](auto kt) {
+        constexpr int k = decltype(kt)::value;
+        if constexpr (k == VM - 1) {
+            __builtin_amdgcn_global_load_lds((const void*)(p_a + (long)p_tile * 1024),
+                                             (lds_void_t*)(smem + p_slot * SLOT + Cfg::AUG + 1024 * (w & 1)), 16, 0, 0);
+        } else {
+            constexpr int which = k & 1, hf = (k >> 1) % (DH / 64), gi = (k >> 1) / (DH / 64);
+            char* dst = smem + p_slot * SLOT + 2 * G8 * w + G8 * gi + 1024 * hf;
+            if constexpr (which)
+                __builtin_amdgcn_global_load_lds((const void*)(p_g0 + (offg[gi][hf] - (unsigned)p_back[gi] * gs2)),
+                                                 (lds_void_t*)(dst + TB), 16, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds((const void*)(p_q0 + (offq[gi][hf] - (unsigned)p_back[gi] * rs2)),
+                                                 (lds_void_t*)dst, 16, 0, 0);
+        }
+    };
+    auto produce_end = [&]() {
+        p_slot = (p_slot + 1) & (NB - 1);
+        // advance; past the last item the last tile is fetched again (harmless, keeps the counts uniform)
+        if (p_tile + 1 < tend) {
+            ++p_tile;
+        } else if (p_n < nseq) {
+            int bh, kb;
+            const int n = next_item(p_n, bh, kb);
+            p_n = n;
+            if (n < nseq) {
+                p_bh = bh;
+                p_kb = kb;
+                producer_set_item();
+            }
+        }
+    };
+    auto produce = [&]() {
+        produce_begin();
+        sfor<VM>([&](auto kt) { produce_piece(kt); });
+        produce_end();
+    };
+
+    // ---- consumer state
+    const unsigned lds0 = lds_addr32(smem);
+    bf16x8 rq[KS + 1], rg[KS + 1];   // row fragments (A operands of S / dP; index KS: the statistics step)
+    bf16x8 ones;                     // B operand of the statistics step: 1 at k = 0, 1, 2 (lanes of the first half)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ones[k] = (bf16_t)((h5 == 0 && k < 3) ? 1.0f : 0.0f);
+
+    // row fragment fg of the unit at byte `ub` (its slot + 0 / UB): fg even: Q rows (S chain), odd: dO rows (dP
+    // chain); k-step fg >> 1, the last one being the statistics row (then ub = slot + AUG + 512 * unit-in-tile)
+    auto read_row = [&](auto gt, unsigned ub) {
+        constexpr int fg = decltype(gt)::value, ks = fg >> 1;
+        if constexpr (ks == KS) {
+            const unsigned a = ub + 16 * l31;
+            if constexpr (fg & 1)
+                rg[KS] = lds_b128<1024>(a);
+            else
+                rq[KS] = lds_b128<0>(a);
+        } else {
+            const unsigned a = ub + ((ks & 1) ? la.row1 : la.row0);
+            if constexpr (fg & 1)
+                rg[ks] = lds_b128<TB + 512 * (ks >> 1)>(a);
+            else
+                rq[ks] = lds_b128<512 * (ks >> 1)>(a);
+        }
+    };
+    // transposed fragment f of stage C of the unit at byte `ub`: f < HF: dO^T for dV -> a[R_TV + 4 f ..],
+    // f >= HF: Q^T for dK -> a[R_TK + 4 (f - HF) ..]; (s2, d) = ((f % HF) / DB, f % DB)
+    auto read_tr = [&](auto ft, unsigned ub) {
+        constexpr int f = decltype(ft)::value;
+        constexpr int which = f / HF, d = f % DB, s2 = (f % HF) / DB;
+        constexpr int o0 = (which ? 0 : TB) + G8 * (2 * s2) + 512 * d, o1 = o0 + G8;
+        constexpr int reg = which ? Cfg::R_TK + 4 * (f - HF) : Cfg::R_TV + 4 * f;
+        lds_tr128_agpr<reg, o0, o1>(ub + la.tr0, ub + la.tr1);
+    };
+    // stage A: S and dP chains, alternating (gap index fg: even = S, odd = dP)
+    auto mfma_a_step = [&](auto gt, f32x16& sc, f32x16& dp) {
+        constexpr int fg = decltype(gt)::value, ks = fg >> 1;
+        if constexpr (fg == 0)
+            mfma_s0<Cfg::R_KF>(sc, rq[0]);
+        else if constexpr (fg == 1)
+            mfma_s0<Cfg::R_VF>(dp, rg[0]);
+        else if constexpr (ks == KS) {
+            if constexpr (fg & 1)
+                mfma_sv(dp, rg[KS], ones);
+            else
+                mfma_sv(sc, rq[KS], ones);
+        } else if constexpr (fg & 1)
+            mfma_s<Cfg::R_VF + 4 * ks>(dp, rg[ks]);
+        else
+            mfma_s<Cfg::R_KF + 4 * ks>(sc, rq[ks]);
+    };
+    auto load_kv = [&](int bh, int kb) {
         // K / V fragments of this lane's key straight into AGPRs; keys past the end read row S-1 (finite data, and
         // their columns of dK / dV are never stored)
-        const long jr = (long)min(j, S - 1) * rs + 8 * h5;
+        const int b = bh / H, h = bh - b * H;
+        const bf16_t* kp = g.qkv + (long)b * S * rs + (long)h * DH + (long)H * DH;
+        const bf16_t* vp = kp + (long)H * DH;
+        const long jr = (long)min(kb * 128 + 32 * w + l31, S - 1) * rs + 8 * h5;
         sfor<KS>([&](auto kt) {
             constexpr int ks = decltype(kt)::value;
             global_b128_to_agpr<Cfg::R_KF + 4 * ks>(kp + jr + ks * 16);
             global_b128_to_agpr<Cfg::R_VF + 4 * ks>(vp + jr + ks * 16);
         });
-        sfor<32 * DB>([&](auto rt) { agpr_zero<decltype(rt)::value>(); });
-    }
-    const float csb = slopes[h] * LOG2E;                 // bias per key step in log2 units
-
-    // units [u0, uendp): an even count (u0 is a multiple of 4, Sp of 64); rows S..Sp-1 carry nl = -inf, so the
-    // padding units contribute exact zeros
-    const int u0 = jb0 / 32;
-    const int uendp = Sp / 32;
-
-    // ---- LDS-DMA staging of one unit: wave w brings rows 8w..8w+7 of Q and dO (DH/64 KiB-pieces each) and its
-    // own copy of the 64 statistics.  Lane l of a piece lands at byte 16 l: 512-B sub-tile l >> 5, row (l >> 2) & 7,
-    // slot l & 3 of the image  off(row, ch) = G8 (row >> 3) + 512 (ch >> 2) + 64 (row & 7) + 16 ((ch & 3) ^ ((row >> 2) & 3)).
-    const int rowin = (lane >> 2) & 7;
-    const int srow = 8 * w + rowin;                      // row of the unit this lane fetches
-    const int sx = (lane & 3) ^ ((srow >> 2) & 3);
-    unsigned colb[DH / 64];
-#pragma unroll
-    for (int hf = 0; hf < DH / 64; ++hf) colb[hf] = (unsigned)((4 * (2 * hf + (lane >> 5)) + sx) * 16);
-    auto stage = [&](int v, int slot) {
-        const int i0 = min(v, uendp - 1) * 32;
-        const int rr = min(i0 + srow, S - 1);            // rows past the end re-read row S-1 (their P is exactly 0)
-        const unsigned oq = (unsigned)rr * (rs * 2u);
-        const unsigned og = (unsigned)rr * (unsigned)(H * DH * 2);
-        char* dst = smem + slot * SLOT + G8 * w;
-#pragma unroll
-        for (int hf = 0; hf < DH / 64; ++hf) {
-            __builtin_amdgcn_global_load_lds((const void*)((const char*)base + (oq + colb[hf])),
-                                             (lds_void_t*)(dst + 1024 * hf), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const void*)((const char*)gp + (og + colb[hf])),
-                                             (lds_void_t*)(dst + UB + 1024 * hf), 16, 0, 0);
-        }
-        const float* sp = (h5 ? nd_bh : nl_bh) + i0 + l31;
-        __builtin_amdgcn_global_load_lds((const void*)sp, (lds_void_t*)(smem + slot * SLOT + 2 * UB + 256 * w), 4, 0, 0);
     };
 
-    const unsigned lds0 = lds_addr32(smem);
-    const unsigned stat_lane = (unsigned)(2 * UB + 256 * w + 16 * h5);
-    // values carried between stages (VGPRs)
-    bf16x8 rq[KS], rg[KS];        // row fragments (A operand of S / dP) of the unit whose stage A comes next
-    f32x4 cnl[4], cnd[4];         // row statistics of the unit whose stage B comes next
-
-    // row fragment g of a unit (g even: Q rows for S, g odd: dO rows for dP; k-step g >> 1)
-    auto read_row = [&](auto gt, unsigned a0, unsigned a1) {
-        constexpr int g = decltype(gt)::value, ks = g >> 1;
-        if constexpr (g & 1)
-            rg[ks] = lds_b128<UB + 512 * (ks >> 1)>((ks & 1) ? a1 : a0);
-        else
-            rq[ks] = lds_b128<512 * (ks >> 1)>((ks & 1) ? a1 : a0);
-    };
-    auto read_stat = [&](auto rt, unsigned as) {
-        constexpr int r = decltype(rt)::value;
-        if constexpr (r < 4)
-            cnl[r] = lds_f128<32 * r>(as);
-        else
-            cnd[r - 4] = lds_f128<128 + 32 * (r - 4)>(as);
-    };
-    // fragment f of stage C -> a[R_TR + 4 f ..]: f < HF: dO^T for dV, f >= HF: Q^T for dK; (s2, d) = ((f % HF) / DB, f % DB)
-    auto read_tr = [&](auto ft, unsigned t0, unsigned t1) {
-        constexpr int f = decltype(ft)::value;
-        constexpr int which = f / HF, d = f % DB, s2 = (f % HF) / DB;
-        constexpr int o0 = (which ? 0 : UB) + G8 * (2 * s2) + 512 * d, o1 = o0 + G8;
-        lds_tr128_agpr<Cfg::R_TR + 4 * f, o0, o1>(t0, t1);
-    };
-    // stage A of one unit: S and dP chains, alternating (gap index g: even = S, odd = dP)
-    auto mfma_a_step = [&](auto gt, f32x16& sc, f32x16& dp) {
-        constexpr int gI = decltype(gt)::value, ks = gI >> 1;
-        if constexpr (gI == 0)
-            mfma_s0<Cfg::R_KF>(sc, rq[0]);
-        else if constexpr (gI == 1)
-            mfma_s0<Cfg::R_VF>(dp, rg[0]);
-        else if constexpr (gI & 1)
-            mfma_s<Cfg::R_VF + 4 * ks>(dp, rg[ks]);
-        else
-            mfma_s<Cfg::R_KF + 4 * ks>(sc, rq[ks]);
-    };
-
-    // ---- prologue: units u0 .. u0+NB-2 into slots 0 .. NB-2
-#pragma unroll
-    for (int s = 0; s < NB - 1; ++s) stage(u0 + s, s);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::VM_PER_UNIT * (NB - 3)) : "memory");   // K, V, units u0 and u0+1
+    // ---- start: first item, its K / V, three tiles in flight
+    int c_n, c_bh = 0, c_kb = 0;
+    c_n = next_item(-1, c_bh, c_kb);
+    if (c_n >= nseq) return;                             // (uniform) nothing to do for this workgroup
+    p_n = c_n;
+    p_bh = c_bh;
+    p_kb = c_kb;
+    producer_set_item();
+    load_kv(c_bh, c_kb);
+    produce();
+    produce();
+    produce();
+    sfor<32 * DB>([&](auto rt) { agpr_zero<decltype(rt)::value>(); });
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * VM) : "memory");      // K, V and the first tile
     PIPE_FENCE();
     __builtin_amdgcn_s_barrier();
     PIPE_FENCE();
+
+    int slot_c = 0;                                      // slot of the tile being consumed
     f32x16 scA, dpA, scB, dpB;
-    {
-        // rows of unit u0 -> A(u0); then statistics of u0 and rows of u0+1
-        const unsigned a0 = lds0 + la.row0, a1 = lds0 + la.row1, as = lds0 + stat_lane;
-        sfor<Cfg::NG_X>([&](auto gt) { read_row(gt, a0, a1); });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        PIPE_FENCE();
-        sfor<Cfg::NG_X>([&](auto gt) { mfma_a_step(gt, scA, dpA); });
-        PIPE_FENCE();
-        const unsigned b0 = a0 + SLOT, b1 = a1 + SLOT;
-        sfor<8>([&](auto rt) { read_stat(rt, as); });
-        sfor<Cfg::NG_X>([&](auto gt) { read_row(gt, b0, b1); });
-        PIPE_FENCE();
-    }
-
-    int slot_c = 0;                                      // slot of the unit in stage B / C
-    int slot_p = NB - 1;                                 // slot of the unit before it (free once every wave is past it)
-    float cjc = csb * (float)(j - 32 * u0);              // bias of key j against the first row of the unit (log2 units)
-    const int umask = u0 + 4;                            // units [u0, umask) can touch the causal diagonal
-
-    // One unit.  (sc, dp) hold S / dP of unit u (from the previous X), (scn, dpn) receive unit u + 1.
-    auto unit = [&](int u, f32x16& sc, f32x16& dp, f32x16& scn, f32x16& dpn) {
-        constexpr int NGX = Cfg::NG_X;
-        constexpr int EPG = 16 / NGX;                     // elements of P per gap of X (1 at dh 128, 2 at dh 64)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // rows of u+1, statistics of u
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::VM_PER_UNIT * (NB - 4)) : "memory");   // my pieces of unit u+2
-        PIPE_FENCE();
-#ifndef PIPE_ABL_NOBAR
-        __builtin_amdgcn_s_barrier();                             // unit u+2 complete; slot of unit u-1 free in every wave
-#endif
-        PIPE_FENCE();
-#ifndef PIPE_ABL_NODMA
-        stage(u + NB - 1, slot_p);
-#endif
-        const int slot_1 = slot_c + 1 >= NB ? slot_c + 1 - NB : slot_c + 1;
-        const int slot_2 = slot_1 + 1 >= NB ? slot_1 + 1 - NB : slot_1 + 1;
-        const unsigned a0 = lds0 + slot_2 * SLOT + la.row0, a1 = lds0 + slot_2 * SLOT + la.row1;   // rows of u+2
-        const unsigned as = lds0 + slot_1 * SLOT + stat_lane;                                      // statistics of u+1
-        const unsigned tc0 = lds0 + slot_c * SLOT + la.tr0, tc1 = lds0 + slot_c * SLOT + la.tr1;   // unit u, transposed
-        if (u < umask) {                                  // wave-uniform, at most 4 units per workgroup
-            const int di = j - 32 * u - 4 * h5;           // row part < di  <=>  query before key
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMA of A(u) must have landed
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                if ((e & 3) + 8 * (e >> 2) < di) sc[e] = -INFINITY;
-        }
-        // ---------------- X(u): A(u+1) MFMAs; between them P of unit u (plain fp32 VALU: v_pk_* does not run beside
-        // the MFMA pipe), the dO^T fragments of unit u, and the row fragments of unit u+2 into the registers that
-        // the MFMA before the gap has just consumed
-        PIPE_FENCE();
-        float pe[16];
-        unsigned pf[8], dsf[8];                           // bf16 pairs: P and dS of unit u
-        sfor<NGX>([&](auto gt) {
-            constexpr int gI = decltype(gt)::value;
-            mfma_a_step(gt, scn, dpn);
+    while (true) {
+        // ================= one item: key block c_kb of (b, h) = c_bh
+        const int b = c_bh / H, h = c_bh - b * H;
+        const int j = c_kb * 128 + 32 * w + l31;
+        const float csb = g.slopes[h] * LOG2E;           // bias per key step in log2 units
+        const int u0 = 4 * c_kb;
+        const int umask = u0 + 4;                        // units [u0, umask) can touch the causal diagonal
+        float cjc = csb * (float)(j - 32 * u0);          // bias of key j against the first row of the unit
+        int n_bh = 0, n_kb = 0;
+        const int n_n = next_item(c_n, n_bh, n_kb);
+        {
+            // not overlapped: A(u0), then the row fragments of unit u0+1 and the dO^T fragments of unit u0
+            const unsigned ub = lds0 + slot_c * SLOT;
+            sfor<NGX>([&](auto gt) {
+                constexpr int fg = decltype(gt)::value;
+                read_row(gt, (fg >> 1) == KS ? ub + Cfg::AUG : ub);
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PIPE_FENCE();
+            sfor<NGX>([&](auto gt) { mfma_a_step(gt, scA, dpA); });
+            PIPE_FENCE();
+            sfor<NGX>([&](auto gt) {
+                constexpr int fg = decltype(gt)::value;
+                read_row(gt, (fg >> 1) == KS ? ub + Cfg::AUG + 512 : ub + UB);
+            });
+            sfor<HF>([&](auto ft) { read_tr(ft, ub); });
+            PIPE_FENCE();
+        }
+
+        // One unit (tile t, half HB).  (sc, dp) hold S / dP of unit u (from the previous X), (scn, dpn) receive u + 1.
+        auto unit = [&](int t, auto hb_tag, f32x16& sc, f32x16& dp, f32x16& scn, f32x16& dpn) {
+            constexpr int HB = decltype(hb_tag)::value;
+            const int u = 2 * t + HB;
+            const int slot_n = (slot_c + 1) & (NB - 1);
+            const unsigned ucur = lds0 + slot_c * SLOT + HB * UB;            // this unit's images
+            const unsigned unext = lds0 + slot_n * SLOT + HB * UB;           // unit u + 2
+            const unsigned u1 = HB ? lds0 + slot_n * SLOT : ucur + UB;       // unit u + 1
+            const unsigned anext = lds0 + slot_n * SLOT + Cfg::AUG + 512 * HB;
+            // rows of u+1 (read during X(u-1)) must have landed; the newest reads (dO^T of unit u) may fly
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * HF < 15 ? 2 * HF : 15) : "memory");
+            PIPE_FENCE();
+            if (HB && t + 1 == tend && n_n < nseq) load_kv(n_bh, n_kb);      // K / V are dead: A(u+1) is never used
+            if (u < umask) {                              // wave-uniform, at most 4 units per item
+                const int di = j - 32 * u - 4 * h5;       // row part < di  <=>  query before key
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMA of A(u) must have landed
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if ((e & 3) + 8 * (e >> 2) < di) sc[e] = -INFINITY;
+            }
+            // ---------------- X(u)
+            PIPE_FENCE();
+            float pe[16];
+            unsigned pf[8], dsf[8];                       // bf16 pairs: P and dS of unit u
+            sfor<NGX>([&](auto gt) {
+                constexpr int fg = decltype(gt)::value;
+                mfma_a_step(gt, scn, dpn);
+                PIPE_FENCE();
+                if constexpr (fg == 0 && HB == 0) {
+                    // tile top, in the shadow of the first MFMA: the next tile must be complete before its rows are
+                    // read below, and the slot of the previous tile is free once every wave is here
+#ifndef PIPE_ABL_NOVMWAIT
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+#endif
+                    PIPE_FENCE();
+#ifndef PIPE_ABL_NOBAR
+                    __builtin_amdgcn_s_barrier();
+#endif
+                    PIPE_FENCE();
+#ifndef PIPE_ABL_NODMA
+                    produce_begin();
+#endif
+                    PIPE_FENCE();
+                }
+#ifndef PIPE_ABL_NODMA
+                if constexpr (HB == 0 && (fg & 1) && (fg >> 1) < VM) {
+                    produce_piece(std::integral_constant<int, (fg >> 1)>{});
+                    if constexpr ((fg >> 1) == VM - 1) produce_end();
+                }
+#endif
 #ifndef PIPE_ABL_NOLDS
-            if constexpr (gI < HF) read_tr(gt, tc0, tc1);
-            read_row(gt, a0, a1);
+                read_row(gt, (fg >> 1) == KS ? anext : unext);
 #endif
 #ifdef PIPE_ABL_NOVALU
-            if (gI == 0)
-                for (int k = 0; k < 8; ++k) pf[k] = dsf[k] = __float_as_uint(sc[k]);
+                if (fg == 0)
+                    for (int k = 0; k < 8; ++k) pf[k] = dsf[k] = __float_as_uint(sc[k]);
 #else
+                if constexpr (fg < 16 / Cfg::EPG) {
 #pragma unroll
-            for (int q = 0; q < EPG; ++q) {
-                constexpr int e0 = gI * EPG;
-                const int e = e0 + q;
-                pe[e] = fast_exp2(fmaf(sc[e], c, cnl[e >> 2][e & 3] + cjc));
-                if (e & 1) pf[e >> 1] = pack2(pe[e - 1], pe[e]);
-            }
+                    for (int q = 0; q < Cfg::EPG; ++q) {
+                        constexpr int e0 = fg * Cfg::EPG;
+                        const int e = e0 + q;
+                        pe[e] = fast_exp2(fma_np(sc[e], g.c, cjc));
+                        if (e & 1) pf[e >> 1] = pack2(pe[e - 1], pe[e]);
+                    }
+                }
 #endif
-            PIPE_FENCE();
-        });
-        // ---------------- Y(u): C(u) MFMAs (dV first, then dK); between the dV MFMAs dS of unit u, the Q^T fragments
-        // of unit u and the statistics of unit u+1
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NGX - HF) : "memory");   // dO^T fragments (the last row reads may fly)
-        PIPE_FENCE();
-        union {
-            unsigned u[4];
-            bf16x8 v;
-        } pb[2], db[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pb[s2].u[k] = pf[4 * s2 + k];
-        PIPE_FENCE();
-        sfor<Cfg::NG_Y>([&](auto gt) {
-            constexpr int f = decltype(gt)::value;
-            constexpr int which = f / HF, d = f % DB, s2 = (f % HF) / DB;
-            if constexpr (f >= HF) {
-                if constexpr (f == HF) {
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) db[s].u[k] = dsf[4 * s + k];
-                    asm volatile("s_nop 1" ::: "memory");         // VALU write of dS -> MFMA read
-                }
-                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(Cfg::y_wait(f)) : "memory");
                 PIPE_FENCE();
-            }
-            if constexpr (which)
-                mfma_acc<Cfg::R_DK + 16 * d, Cfg::R_TR + 4 * f>(db[s2].v);
-            else
-                mfma_acc<Cfg::R_DV + 16 * d, Cfg::R_TR + 4 * f>(pb[s2].v);
+            });
+            // ---------------- Y(u): dV MFMAs (with dS of unit u and the Q^T fragments of unit u between them), then dK
+            // MFMAs (with the dO^T fragments of unit u+1 between them)
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NGX < 15 ? NGX : 15) : "memory");   // dO^T fragments of unit u
             PIPE_FENCE();
-            if constexpr (f < HF) {
-#ifndef PIPE_ABL_NOVALU
-                // dS pairs: 8 / HF per gap
+            union {
+                unsigned u[4];
+                bf16x8 v;
+            } pb[2], db[2];
 #pragma unroll
-                for (int q = 0; q < 8 / HF; ++q) {
-                    constexpr int pr0 = f * (8 / HF);
-                    const int pr = pr0 + q, e = 2 * pr;
-                    const float d0 = pe[e] * (dp[e] + cnd[e >> 2][e & 3]);
-                    const float d1 = pe[e + 1] * (dp[e + 1] + cnd[e >> 2][(e & 3) + 1]);
-                    dsf[pr] = pack2(d0, d1);
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pb[s2].u[k] = pf[4 * s2 + k];
+            PIPE_FENCE();
+            sfor<Cfg::NG_Y>([&](auto gt) {
+                constexpr int f = decltype(gt)::value;
+                constexpr int d = f % DB, s2 = (f % HF) / DB;
+                if constexpr (f >= HF) {
+                    if constexpr (f == HF) {
+#pragma unroll
+                        for (int s = 0; s < 2; ++s)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) db[s].u[k] = dsf[4 * s + k];
+                        asm volatile("s_nop 1" ::: "memory");     // VALU write of dS -> MFMA read
+                    }
+                    // Q^T fragment f - HF was read in gap f - HF; 2 (HF - 1) reads have been issued since
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (HF - 1)) : "memory");
+                    PIPE_FENCE();
+                    mfma_acc<Cfg::R_DK + 16 * d, Cfg::R_TK + 4 * (f - HF)>(db[s2].v);
+                } else {
+                    mfma_acc<Cfg::R_DV + 16 * d, Cfg::R_TV + 4 * f>(pb[s2].v);
                 }
+                PIPE_FENCE();
+                if constexpr (f < HF) {
+#ifndef PIPE_ABL_NOVALU
+#pragma unroll
+                    for (int q = 0; q < 8 / HF; ++q) {
+                        constexpr int pr0 = f * (8 / HF);
+                        const int pr = pr0 + q, e = 2 * pr;
+                        dsf[pr] = pack2(mul_np(pe[e], dp[e]), mul_np(pe[e + 1], dp[e + 1]));
+                    }
 #endif
 #ifndef PIPE_ABL_NOLDS
-                read_tr(std::integral_constant<int, f + HF>{}, tc0, tc1);
-                sfor<Cfg::SPG>([&](auto st) {
-                    // cnl is dead since X; cnd[k] is last used by the dS pairs of gap (2k+1) * HF / 8
-                    constexpr int r = f * Cfg::SPG + decltype(st)::value;
-                    read_stat(std::integral_constant<int, r>{}, as);
-                });
+                    read_tr(std::integral_constant<int, f + HF>{}, ucur);
 #endif
-            }
-            PIPE_FENCE();
-        });
-        slot_p = slot_c;
-        slot_c = slot_1;
-        cjc -= 32.f * csb;
-    };
-
-    for (int u = u0; u < uendp; u += 2) {
-        unit(u, scA, dpA, scB, dpB);
-        unit(u + 1, scB, dpB, scA, dpA);
-    }
-    // drain the clamped re-loads and reads of the tail; the last MFMAs must have written dK / dV before they are
-    // read back (16 passes; nothing tells the compiler about the dependency)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-    PIPE_FENCE();
-
-    if (jok) {
-        bf16_t* op = dqkv + ((long)b * S + j) * rs + (long)h * DH;
-        sfor<DB>([&](auto dt) {
-            constexpr int d = decltype(dt)::value;
-            sfor<4>([&](auto gt) {
-                constexpr int g = decltype(gt)::value;
-                bf16x4 a, v;
-                a[0] = (bf16_t)(agpr_get<Cfg::R_DK + 16 * d + 4 * g + 0>() * scale);
-                a[1] = (bf16_t)(agpr_get<Cfg::R_DK + 16 * d + 4 * g + 1>() * scale);
-                a[2] = (bf16_t)(agpr_get<Cfg::R_DK + 16 * d + 4 * g + 2>() * scale);
-                a[3] = (bf16_t)(agpr_get<Cfg::R_DK + 16 * d + 4 * g + 3>() * scale);
-                v[0] = (bf16_t)agpr_get<Cfg::R_DV + 16 * d + 4 * g + 0>();
-                v[1] = (bf16_t)agpr_get<Cfg::R_DV + 16 * d + 4 * g + 1>();
-                v[2] = (bf16_t)agpr_get<Cfg::R_DV + 16 * d + 4 * g + 2>();
-                v[3] = (bf16_t)agpr_get<Cfg::R_DV + 16 * d + 4 * g + 3>();
-                *reinterpret_cast<bf16x4*>(op + (long)H * DH + 32 * d + 8 * g + 4 * h5) = a;
-                *reinterpret_cast<bf16x4*>(op + 2L * H * DH + 32 * d + 8 * g + 4 * h5) = v;
+                } else {
+#ifndef PIPE_ABL_NOLDS
+                    read_tr(std::integral_constant<int, f - HF>{}, u1);
+#endif
+                }
+                PIPE_FENCE();
             });
-        });
+            cjc -= 32.f * csb;
+        };
+
+        for (int t = 2 * c_kb; t < tend; ++t) {
+            unit(t, std::integral_constant<int, 0>{}, scA, dpA, scB, dpB);
+            unit(t, std::integral_constant<int, 1>{}, scB, dpB, scA, dpA);
+            slot_c = (slot_c + 1) & (NB - 1);
+        }
+
+        // ---- item done.  The last MFMAs must have written dK / dV before they are read back (16 passes; nothing
+        // tells the compiler about the dependency).
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        PIPE_FENCE();
+#ifndef PIPE_ABL_NOSTORE
+        {
+            // dK^T / dV^T have the key on the lane and dh down the registers: written out directly, every store
+            // instruction would scatter 8-byte pieces over 64 rows.  Each wave turns its 32 keys x 64 columns at a time
+            // through 4 KiB of LDS (16-byte chunks XOR-swizzled with the row) and stores 128-byte row segments.
+            const unsigned eb = lds0 + EPI + 4096 * w;
+            const int erow = lane >> 3, ech = lane & 7;
+            bf16_t* const orow = g.dqkv + ((long)b * S + c_kb * 128 + 32 * w) * rs + (long)h * DH;
+            sfor<2 * (DH / 64)>([&](auto pt) {
+                constexpr int mat = decltype(pt)::value / (DH / 64), half = decltype(pt)::value % (DH / 64);   // mat 0: dK, 1: dV
+                sfor<2>([&](auto dt) {
+                    constexpr int db = 2 * half + decltype(dt)::value;
+                    sfor<4>([&](auto gt) {
+                        constexpr int gg = decltype(gt)::value;
+                        constexpr int r0 = (mat ? Cfg::R_DV : Cfg::R_DK) + 16 * db + 4 * gg;
+                        const float sc_ = mat ? 1.f : g.scale;
+                        bf16x4 v;
+                        v[0] = (bf16_t)(agpr_get<r0 + 0>() * sc_);
+                        v[1] = (bf16_t)(agpr_get<r0 + 1>() * sc_);
+                        v[2] = (bf16_t)(agpr_get<r0 + 2>() * sc_);
+                        v[3] = (bf16_t)(agpr_get<r0 + 3>() * sc_);
+                        const int c16 = 4 * (db & 1) + gg;
+                        lds_write_b64(eb + l31 * 128 + ((c16 ^ (l31 & 7)) * 16) + 8 * h5, v);
+                    });
+                });
+                // the wave reads back what it wrote itself: LDS operations of one wave complete in order
+                bf16x8 ov[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 8 * i + erow;
+                    ov[i] = lds_b128<0>(eb + row * 128 + ((ech ^ (row & 7)) * 16));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                PIPE_FENCE();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 8 * i + erow;
+                    if (c_kb * 128 + 32 * w + row < S)
+                        *reinterpret_cast<bf16x8*>(orow + (long)row * rs + (long)(1 + mat) * H * DH + 64 * half + 8 * ech) = ov[i];
+                }
+            });
+        }
+#endif
+        PIPE_FENCE();
+        if (n_n >= nseq) break;
+        c_n = n_n;
+        c_bh = n_bh;
+        c_kb = n_kb;
+        sfor<32 * DB>([&](auto rt) { agpr_zero<decltype(rt)::value>(); });
+        // the next item's K / V (requested a unit ago); every tile requested before them has landed as well, and the
+        // first of them was complete in every wave at the last tile top
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        PIPE_FENCE();
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-fetched tail tiles
 }
 
 }  // namespace
 
-#pragma clang attribute pop
+long mgx_attn_bwd_pipe_stats_floats(int B, int S, int H) { return 9L * B * H * ((S + 63) / 64 * 64); }
 
-long mgx_attn_bwd_pipe_stats_floats(int B, int S, int H) { return 2L * B * H * ((S + 63) / 64 * 64); }
-
-// statistics pre-pass + dK/dV; `stats` holds mgx_attn_bwd_pipe_stats_floats(B, S, H) floats: nl then nd
+// statistics pre-pass + dK/dV; `stats` holds mgx_attn_bwd_pipe_stats_floats(B, S, H) floats: nla | nda | nd32
 int mgx_attn_bwd_dkv_pipe(const void* dout, const void* qkv, const void* out, const float* lse, const float* slopes,
                           void* dqkv, float* stats, int B, int S, int H, int dh, hipStream_t st) {
     const int Sp = (S + 63) / 64 * 64;
-    float* nl = stats;
-    float* nd = stats + (long)B * H * Sp;
+    const long rows = (long)B * H * Sp;
+    bf16_t* nla = (bf16_t*)stats;
+    bf16_t* nda = (bf16_t*)(stats + 4 * rows);
+    float* nd32 = stats + 8 * rows;
     const float scale = 1.0f / sqrtf((float)dh);
     const float c = LOG2E * scale;
     const long n_chunks = (long)B * Sp * H * (dh / 8);
     dim3 gs((unsigned)((n_chunks + 255) / 256));
-    dim3 gk(H, B, (S + 127) / 128);
+    DkvArgs a{(const bf16_t*)dout, (const bf16_t*)qkv, nla, nda, slopes, (bf16_t*)dqkv, B, S, Sp, H, c, scale, 0, 0, 0};
+    a.nkb = (S + 127) / 128;
+    a.np = (a.nkb + 1) / 2;
+    a.nwork = B * H * a.np;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MGX_ELAUNCH;
+        n_cu = prop.multiProcessorCount;
+    }
+    const int grid = a.nwork < n_cu ? a.nwork : n_cu;     // one persistent workgroup per CU
     if (dh == 64) {
         hipLaunchKernelGGL((attn_bwd_stats_kernel<64>), gs, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
-                           lse, slopes, nl, nd, n_chunks, S, Sp, H);
+                           lse, slopes, nla, nda, nd32, n_chunks, S, Sp, H, 1.f / c);
         MGX_CHECK_LAUNCH("attn_bwd_stats");
-        hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<64>), gk, dim3(256), 0, st, (const bf16_t*)dout,
-                           (const bf16_t*)qkv, nl, nd, slopes, (bf16_t*)dqkv, S, Sp, H, c, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<64>), dim3(grid), dim3(256), 0, st, a);
     } else {
         hipLaunchKernelGGL((attn_bwd_stats_kernel<128>), gs, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
-                           lse, slopes, nl, nd, n_chunks, S, Sp, H);
+                           lse, slopes, nla, nda, nd32, n_chunks, S, Sp, H, 1.f / c);
         MGX_CHECK_LAUNCH("attn_bwd_stats");
-        hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<128>), gk, dim3(256), 0, st, (const bf16_t*)dout,
-                           (const bf16_t*)qkv, nl, nd, slopes, (bf16_t*)dqkv, S, Sp, H, c, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_pipe_kernel<128>), dim3(grid), dim3(256), 0, st, a);
     }
     MGX_CHECK_LAUNCH("attn_bwd_dkv_pipe");
     return MGX_OK;
