@@ -16,109 +16,9 @@
 // later stage (more than that per gap does not hide under an MFMA: tools/mfma_overlap_lab2.cpp).
 // All LDS reads are inline asm with explicit s_waitcnt (hipcc would otherwise drain vmcnt before every read that
 // follows an LDS-DMA).
-#include <type_traits>
-#include <utility>
-#include "attn_mfma_common.h"
+#include "attn_pipe_common.h"
 
 namespace {
-
-typedef __attribute__((address_space(3))) char lds_char_t;
-typedef __attribute__((address_space(3))) void lds_void_t;
-__device__ __forceinline__ unsigned lds_addr32(const char* p) { return (unsigned)(unsigned long)(lds_char_t*)p; }
-
-template <int OFF>
-__device__ __forceinline__ bf16x8 lds_b128(unsigned addr) {
-    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
-    bf16x8 r;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
-    return r;
-}
-
-__device__ __forceinline__ void lds_write_b64(unsigned addr, const bf16x4& v) {
-    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-
-// ---- AGPRs are allocated BY HAND.  hipcc keeps every MFMA accumulator of a 1-wave-per-SIMD kernel in AGPRs and copies
-// S / dP to VGPRs and back around each VALU use, and values with an "a" inline-asm constraint are shuttled through
-// VGPRs as well; so everything that lives in the AGPR half of the register file (dK / dV accumulators, the K / V
-// fragments, the transposed Q / dO fragments) is named literally in the asm text (register numbers are template
-// constants printed through "n" operands) and never exists as a compiler value.  The compiler owns the VGPR half
-// (a kernel of this shape needs < 256 of them, so it has no reason to spill into AGPRs; check the ISA after a change:
-// no v_accvgpr_* outside the item prologue / epilogue).
-// Its hazard recogniser does not see these MFMAs: the pipeline keeps every VALU producer / consumer of an MFMA
-// operand a whole stage away, and explicit s_nop's guard the places where that is not so.
-template <int R0, int OFF0, int OFF1>
-__device__ __forceinline__ void lds_tr128_agpr(unsigned a0, unsigned a1) {
-    static_assert(OFF0 >= 0 && OFF1 < 65536, "ds offset field is 16 bits");
-    asm volatile("ds_read_b64_tr_b16 a[%2:%3], %0 offset:%6\n\tds_read_b64_tr_b16 a[%4:%5], %1 offset:%7"
-                 :
-                 : "v"(a0), "v"(a1), "n"(R0), "n"(R0 + 1), "n"(R0 + 2), "n"(R0 + 3), "n"(OFF0), "n"(OFF1));
-}
-// S / dP: D (VGPRs) = A (row fragment, VGPRs) x B (K or V fragment, a[RB..RB+3]) [+ D]
-template <int RB>
-__device__ __forceinline__ void mfma_s0(f32x16& d, const bf16x8& a) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], 0" : "=&v"(d) : "v"(a), "n"(RB), "n"(RB + 3));
-}
-template <int RB>
-__device__ __forceinline__ void mfma_s(f32x16& d, const bf16x8& a) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0" : "+v"(d) : "v"(a), "n"(RB), "n"(RB + 3));
-}
-// the statistics step: B (ones in k = 0..2) in VGPRs
-__device__ __forceinline__ void mfma_sv(f32x16& d, const bf16x8& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
-}
-// dV / dK: a[RD..RD+15] += A (transposed fragment, a[RA..RA+3]) x B (P or dS, VGPRs)
-template <int RD, int RA>
-__device__ __forceinline__ void mfma_acc(const bf16x8& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 a[%1:%2], a[%3:%4], %0, a[%1:%2]"
-                 :
-                 : "v"(b), "n"(RD), "n"(RD + 15), "n"(RA), "n"(RA + 3));
-}
-template <int R>
-__device__ __forceinline__ void agpr_zero() {
-    asm volatile("v_accvgpr_write_b32 a[%0], 0" ::"n"(R));
-}
-template <int R>
-__device__ __forceinline__ float agpr_get() {
-    float v;
-    asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(v) : "n"(R));
-    return v;
-}
-template <int R0>
-__device__ __forceinline__ void global_b128_to_agpr(const void* p) {
-    asm volatile("global_load_dwordx4 a[%1:%2], %0, off" ::"v"(p), "n"(R0), "n"(R0 + 3) : "memory");
-}
-// fp32 VALU the compiler may not pair into v_pk_fma_f32 / v_pk_mul_f32 (those do not run beside the MFMA pipe)
-__device__ __forceinline__ float fma_np(float a, float b, float c) {
-    float r;
-    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float mul_np(float a, float b) {
-    float r;
-    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-template <int... I, typename F>
-__device__ __forceinline__ void sfor_impl(std::integer_sequence<int, I...>, F&& f) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void sfor(F&& f) {
-    sfor_impl(std::make_integer_sequence<int, N>{}, f);
-}
-#define PIPE_FENCE() __builtin_amdgcn_sched_barrier(0)
-
-__device__ __forceinline__ unsigned pack2(float a, float b) {
-    typedef __attribute__((ext_vector_type(2))) float f2;
-    union {
-        bf16x2 v;
-        unsigned u;
-    } r;
-    r.v = __builtin_convertvector(f2{a, b}, bf16x2);
-    return r.u;
-}
 
 // Row statistics for the backward, rows padded to Sp (a multiple of 64):
 //   nla[b,h,i] (16 B) = -(slope_h * (i mod 32) + lse) * log2e / c  split into three bf16 (hi, mid, lo) + five zeros:
@@ -511,32 +411,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pipe_kernel(DkvArgs g) {
             // MFMAs (with the dO^T fragments of unit u+1 between them)
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NGX < 15 ? NGX : 15) : "memory");   // dO^T fragments of unit u
             PIPE_FENCE();
-            union {
-                unsigned u[4];
-                bf16x8 v;
-            } pb[2], db[2];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) pb[s2].u[k] = pf[4 * s2 + k];
+            const bf16x8 pb[2] = {words_to_frag(pf[0], pf[1], pf[2], pf[3]), words_to_frag(pf[4], pf[5], pf[6], pf[7])};
+            bf16x8 db[2];
             PIPE_FENCE();
             sfor<Cfg::NG_Y>([&](auto gt) {
                 constexpr int f = decltype(gt)::value;
                 constexpr int d = f % DB, s2 = (f % HF) / DB;
                 if constexpr (f >= HF) {
                     if constexpr (f == HF) {
-#pragma unroll
-                        for (int s = 0; s < 2; ++s)
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) db[s].u[k] = dsf[4 * s + k];
+                        db[0] = words_to_frag(dsf[0], dsf[1], dsf[2], dsf[3]);
+                        db[1] = words_to_frag(dsf[4], dsf[5], dsf[6], dsf[7]);
                         asm volatile("s_nop 1" ::: "memory");     // VALU write of dS -> MFMA read
                     }
                     // Q^T fragment f - HF was read in gap f - HF; 2 (HF - 1) reads have been issued since
                     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (HF - 1)) : "memory");
                     PIPE_FENCE();
-                    mfma_acc<Cfg::R_DK + 16 * d, Cfg::R_TK + 4 * (f - HF)>(db[s2].v);
+                    mfma_acc<Cfg::R_DK + 16 * d, Cfg::R_TK + 4 * (f - HF)>(db[s2]);
                 } else {
-                    mfma_acc<Cfg::R_DV + 16 * d, Cfg::R_TV + 4 * f>(pb[s2].v);
+                    mfma_acc<Cfg::R_DV + 16 * d, Cfg::R_TV + 4 * f>(pb[s2]);
                 }
                 PIPE_FENCE();
                 if constexpr (f < HF) {

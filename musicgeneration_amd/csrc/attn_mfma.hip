@@ -22,6 +22,9 @@
 
 // attn_bwd_pipe.hip
 long mgx_attn_bwd_pipe_stats_floats(int B, int S, int H);
+// attn_bwd_dq_pipe.hip
+int mgx_attn_bwd_dq_pipe(const void* dout, const void* qkv, const float* lse, const float* nd32, const float* slopes,
+                         void* dqkv, int B, int S, int H, int dh, hipStream_t st);
 int mgx_attn_bwd_dkv_pipe(const void* dout, const void* qkv, const void* out, const float* lse, const float* slopes,
                           void* dqkv, float* stats, int B, int S, int H, int dh, hipStream_t st);
 
@@ -479,11 +482,7 @@ int launch_bwd_mfma(const void* dout, const void* qkv, const void* out, const fl
     const int rc = mgx_attn_bwd_dkv_pipe(dout, qkv, out, lse, slopes, dqkv, ws, B, S, H, DH, st);
     if (rc != MGX_OK) return rc;
     const float* nd = ws + 8L * B * H * Sp;          // nla | nda (16 B per row each) | nd32
-    dim3 grid(H, B, (S + 32 * NW - 1) / (32 * NW));
-    hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DH, NW>), grid, dim3(64 * NW), 0, st, (const bf16_t*)dout, (const bf16_t*)qkv,
-                       lse, nd, slopes, (bf16_t*)dqkv, S, Sp, H, c, scale);
-    MGX_CHECK_LAUNCH("attn_bwd_dq_mfma");
-    return MGX_OK;
+    return mgx_attn_bwd_dq_pipe(dout, qkv, lse, nd, slopes, dqkv, B, S, H, DH, st);
 }
 
 }  // namespace
