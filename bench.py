@@ -250,7 +250,7 @@ def main():
               "rel_attn_fwd": "rel_fwd_mfma_kernel (skew relative flash forward; QK^T + QE^T + PV at half the square)",
               "rel_attn_bwd": "rel_bwd_dkv + rel_bwd_dq + rel_bwd_de + delta (6 products at half the square; 16 executed: "
                               "S, dP and Q.E^T are recomputed in each of the three kernels)",
-              "alibi_attn_bwd": "attn_bwd_dkv_mfma_kernel + attn_bwd_dq_mfma_kernel + delta (5 products at half the square)",
+              "alibi_attn_bwd": "attn_bwd_stats_kernel + attn_bwd_dkv_pipe_kernel + attn_bwd_dq_pipe_kernel (5 products at half the square)",
               "gemm_nt": "gemm_nt_kernel (every x.W and dy.W^T projection of the blocks and the head: forward + dgrad, "
                          "bias / residual / activation-backward epilogues)",
               "gemm_tn": "gemm_tn_kernel + splitk_reduce_kernel (weight gradients of the blocks, split-K fp32 slabs)",

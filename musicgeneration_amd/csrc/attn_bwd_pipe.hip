@@ -369,32 +369,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pipe_kernel(DkvArgs g) {
                 if constexpr (fg == 0 && HB == 0) {
                     // tile top, in the shadow of the first MFMA: the next tile must be complete before its rows are
                     // read below, and the slot of the previous tile is free once every wave is here
-#ifndef PIPE_ABL_NOVMWAIT
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
-#endif
                     PIPE_FENCE();
-#ifndef PIPE_ABL_NOBAR
                     __builtin_amdgcn_s_barrier();
-#endif
                     PIPE_FENCE();
-#ifndef PIPE_ABL_NODMA
                     produce_begin();
-#endif
                     PIPE_FENCE();
                 }
-#ifndef PIPE_ABL_NODMA
                 if constexpr (HB == 0 && (fg & 1) && (fg >> 1) < VM) {
                     produce_piece(std::integral_constant<int, (fg >> 1)>{});
                     if constexpr ((fg >> 1) == VM - 1) produce_end();
                 }
-#endif
-#ifndef PIPE_ABL_NOLDS
                 read_row(gt, (fg >> 1) == KS ? anext : unext);
-#endif
-#ifdef PIPE_ABL_NOVALU
-                if (fg == 0)
-                    for (int k = 0; k < 8; ++k) pf[k] = dsf[k] = __float_as_uint(sc[k]);
-#else
                 if constexpr (fg < 16 / Cfg::EPG) {
 #pragma unroll
                     for (int q = 0; q < Cfg::EPG; ++q) {
@@ -404,7 +390,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pipe_kernel(DkvArgs g) {
                         if (e & 1) pf[e >> 1] = pack2(pe[e - 1], pe[e]);
                     }
                 }
-#endif
                 PIPE_FENCE();
             });
             // ---------------- Y(u): dV MFMAs (with dS of unit u and the Q^T fragments of unit u between them), then dK
@@ -432,21 +417,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pipe_kernel(DkvArgs g) {
                 }
                 PIPE_FENCE();
                 if constexpr (f < HF) {
-#ifndef PIPE_ABL_NOVALU
 #pragma unroll
                     for (int q = 0; q < 8 / HF; ++q) {
                         constexpr int pr0 = f * (8 / HF);
                         const int pr = pr0 + q, e = 2 * pr;
                         dsf[pr] = pack2(mul_np(pe[e], dp[e]), mul_np(pe[e + 1], dp[e + 1]));
                     }
-#endif
-#ifndef PIPE_ABL_NOLDS
                     read_tr(std::integral_constant<int, f + HF>{}, ucur);
-#endif
                 } else {
-#ifndef PIPE_ABL_NOLDS
                     read_tr(std::integral_constant<int, f - HF>{}, u1);
-#endif
                 }
                 PIPE_FENCE();
             });
@@ -463,7 +442,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pipe_kernel(DkvArgs g) {
         // tells the compiler about the dependency).
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
         PIPE_FENCE();
-#ifndef PIPE_ABL_NOSTORE
         {
             // dK^T / dV^T have the key on the lane and dh down the registers: written out directly, every store
             // instruction would scatter 8-byte pieces over 64 rows.  Each wave turns its 32 keys x 64 columns at a time
@@ -505,7 +483,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pipe_kernel(DkvArgs g) {
                 }
             });
         }
-#endif
         PIPE_FENCE();
         if (n_n >= nseq) break;
         c_n = n_n;

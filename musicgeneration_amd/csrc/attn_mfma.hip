@@ -109,12 +109,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_mfma_kernel(const bf16_t*
             for (int ks = 0; ks < DH / 16; ++ks)
 #pragma unroll
                 for (int tb = 0; tb < 2; ++tb)
-#ifdef MGX_ABL_FWD_NOLDS                 // timing experiment only: results are wrong
-                    s[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[(ks + 1) % (DH / 16)], qf[ks], s[tb], 0, 0, 0);
-#else
                     s[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(Ks + la.row_read(tb, ks)), qf[ks],
                                                                    s[tb], 0, 0, 0);
-#endif
             if (j0 + 63 > qw0) {                          // diagonal tile: causal mask
                 const int dj = qi - j0 - 4 * h5;          // key offset (r-part) must be <= dj
 #pragma unroll
@@ -149,11 +145,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_mfma_kernel(const bf16_t*
             for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-#ifdef MGX_ABL_FWD_NOEXP                 // timing experiment only: results are wrong
-                    const float p = s[tb][r];
-#else
                     const float p = fast_exp2(fmaf(s[tb][r], c, -mc));
-#endif
                     s[tb][r] = p;
                     psum += p;
                 }
@@ -165,11 +157,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_mfma_kernel(const bf16_t*
                     const bf16x8 pf = pack8(s[tb], 8 * s2);
 #pragma unroll
                     for (int d = 0; d < DH / 32; ++d) {
-#ifdef MGX_ABL_FWD_NOLDS                 // timing experiment only: results are wrong
-                        const bf16x8 vf = qf[(4 * tb + 2 * s2 + d) % (DH / 16)];
-#else
                         const bf16x8 vf = lds_read_tr_pair(Vs + la.tr_read(tb, s2, 0, d), Vs + la.tr_read(tb, s2, 1, d));
-#endif
                         o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
                     }
                 }
@@ -195,294 +183,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_mfma_kernel(const bf16_t*
 
 
 // ===========================================================================
-// backward
+// backward: statistics pre-pass + dK/dV kernel (attn_bwd_pipe.hip), then the dQ kernel (attn_bwd_dq_pipe.hip)
 // ===========================================================================
-// dQ: query on the lane (as the forward).  Per 32-key block:
-//   S^T = K.Q^T (+bias)   dP^T = V.dO^T (-delta)   dS^T = P^T*(dP^T)*scale   dQ^T += K^T.dS^T
-template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW, MGX_DQ_OCC) void attn_bwd_dq_mfma_kernel(
-    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
-    const float* __restrict__ nd /* -delta, rows padded to Sp */, const float* __restrict__ slopes,
-    bf16_t* __restrict__ dqkv, int S, int Sp, int H, float c, float scale) {
-    constexpr int NT = 64 * NW, QB = 32 * NW, TB = Img<DH>::TILE_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[4 * TB];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int l31 = lane & 31, h5 = lane >> 5;
-    const int qb = gridDim.z - 1 - blockIdx.z;
-    const int q0 = qb * QB, qw0 = q0 + 32 * w;
-    const int b = blockIdx.y, h = blockIdx.x;
-    const unsigned rs = 3u * H * DH;
-    const bf16_t* base = qkv + (long)b * S * rs + (long)h * DH;
-    const bf16_t* kp = base + (long)H * DH;
-    const bf16_t* vp = base + 2L * H * DH;
-    const bf16_t* gp = dout + (long)b * S * H * DH + (long)h * DH;
-    const LaneAddr<DH> la(lane);
-
-    const int qi = qw0 + l31;
-    const bool qok = qi < S;
-    bf16x8 qf[DH / 16], gf[DH / 16];
-#pragma unroll
-    for (int ks = 0; ks < DH / 16; ++ks) {
-        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        qf[ks] = qok ? *reinterpret_cast<const bf16x8*>(base + (long)qi * rs + ks * 16 + 8 * h5) : z;
-        gf[ks] = qok ? *reinterpret_cast<const bf16x8*>(gp + (long)qi * H * DH + ks * 16 + 8 * h5) : z;
-    }
-    const float lse2 = qok ? lse[((long)b * H + h) * S + qi] * LOG2E : INFINITY;
-    const float ndelta = qok ? nd[((long)b * H + h) * Sp + qi] : 0.f;
-    const float sb = slopes[h] * LOG2E / c;
-
-    f32x16 dq[DH / 32];
-#pragma unroll
-    for (int d = 0; d < DH / 32; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
-
-    const int kmax = min(q0 + QB, S);
-    const int ntiles = (kmax + 63) / 64;
-    TileRegs<DH, NT> kr, vr;
-    tile_load<DH, NT>(kr, kp, rs, 0, S, tid);
-    tile_load<DH, NT>(vr, vp, rs, 0, S, tid);
-    tile_store<DH, NT>(kr, smem, tid);
-    tile_store<DH, NT>(vr, smem + TB, tid);
-    if (ntiles > 1) {
-        tile_load<DH, NT>(kr, kp, rs, 64, S, tid);
-        tile_load<DH, NT>(vr, vp, rs, 64, S, tid);
-    }
-    __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const int j0 = t * 64;
-        const char* Ks = smem + (t & 1) * 2 * TB;
-        const char* Vs = Ks + TB;
-        if (t + 1 < ntiles) {
-            char* Kn = smem + ((t + 1) & 1) * 2 * TB;
-            tile_store<DH, NT>(kr, Kn, tid);
-            tile_store<DH, NT>(vr, Kn + TB, tid);
-        }
-        if (t + 2 < ntiles) {
-            tile_load<DH, NT>(kr, kp, rs, j0 + 128, S, tid);
-            tile_load<DH, NT>(vr, vp, rs, j0 + 128, S, tid);
-        }
-        if (j0 <= qw0 + 31) {
-            const float lb = sb * (float)(j0 + 4 * h5 - qi);
-            const int dj = qi - j0 - 4 * h5;
-            const bool diag = j0 + 63 > qw0;
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb) {
-                if (j0 + 32 * tb > qw0 + 31) continue;             // wave-uniform: block fully masked
-                f32x16 sc, dp;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    sc[r] = lb + sb * (float)(32 * tb + (r & 3) + 8 * (r >> 2));
-                    dp[r] = ndelta;
-                }
-#pragma unroll
-                for (int ks = 0; ks < DH / 16; ++ks) {
-                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(Ks + la.row_read(tb, ks)), qf[ks], sc, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(Vs + la.row_read(tb, ks)), gf[ks], dp, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float p = fast_exp2(fmaf(sc[r], c, -lse2));
-                    if (diag && (32 * tb + (r & 3) + 8 * (r >> 2) > dj)) p = 0.f;
-                    sc[r] = p * dp[r] * scale;
-                }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 dsf = pack8(sc, 8 * s2);
-#pragma unroll
-                    for (int d = 0; d < DH / 32; ++d) {
-                        const bf16x8 kt = lds_read_tr_pair(Ks + la.tr_read(tb, s2, 0, d), Ks + la.tr_read(tb, s2, 1, d));
-                        dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, dsf, dq[d], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (qok) {
-        bf16_t* op = dqkv + ((long)b * S + qi) * rs + (long)h * DH;
-#pragma unroll
-        for (int d = 0; d < DH / 32; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 v;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = (bf16_t)dq[d][4 * g + k];
-                *reinterpret_cast<bf16x4*>(op + 32 * d + 8 * g + 4 * h5) = v;
-            }
-    }
-}
-
-// dK, dV: key on the lane.  Per 32-query block of a 64-query tile:
-//   S = Q.K^T (+bias-lse)  dP = dO.V^T (-delta)  P = exp2, dS = P*dP*scale
-//   dV^T += dO^T.P         dK^T += Q^T.dS        (P, dS straight from the accumulators)
-template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW, MGX_DKV_OCC) void attn_bwd_dkv_mfma_kernel(
-    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
-    const float* __restrict__ delta, const float* __restrict__ slopes, bf16_t* __restrict__ dqkv, int S, int H,
-    float c, float scale) {
-    constexpr int NT = 64 * NW, KB = 32 * NW, TB = Img<DH>::TILE_BYTES;
-    // 2 buffers x (Q image, dO image), then 2 x (row stats L[64], -delta[64])
-    __shared__ __attribute__((aligned(16))) char smem[4 * TB + 4 * 64 * sizeof(float)];
-    float* stats = reinterpret_cast<float*>(smem + 4 * TB);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int l31 = lane & 31, h5 = lane >> 5;
-    const int jb0 = blockIdx.z * KB, jw0 = jb0 + 32 * w;      // early key blocks (most queries) first
-    const int b = blockIdx.y, h = blockIdx.x;
-    const unsigned rs = 3u * H * DH;
-    const bf16_t* base = qkv + (long)b * S * rs + (long)h * DH;
-    const bf16_t* kp = base + (long)H * DH;
-    const bf16_t* vp = base + 2L * H * DH;
-    const bf16_t* gp = dout + (long)b * S * H * DH + (long)h * DH;
-    const float* lse_bh = lse + ((long)b * H + h) * S;
-    const float* delta_bh = delta + ((long)b * H + h) * S;
-    const LaneAddr<DH> la(lane);
-
-    const int j = jw0 + l31;
-    const bool jok = j < S;
-    bf16x8 kf[DH / 16], vf[DH / 16];
-#pragma unroll
-    for (int ks = 0; ks < DH / 16; ++ks) {
-        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        kf[ks] = jok ? *reinterpret_cast<const bf16x8*>(kp + (long)j * rs + ks * 16 + 8 * h5) : z;
-        vf[ks] = jok ? *reinterpret_cast<const bf16x8*>(vp + (long)j * rs + ks * 16 + 8 * h5) : z;
-    }
-    const float sb = slopes[h] * LOG2E / c;
-    const float inv_c = 1.f / c;
-
-    f32x16 dk[DH / 32], dv[DH / 32];
-#pragma unroll
-    for (int d = 0; d < DH / 32; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dk[d][r] = dv[d][r] = 0.f;
-
-    const int t0 = jb0 / 64;
-    const int ntiles = (S + 63) / 64;
-    TileRegs<DH, NT> qr, gr;
-    float r_lse = 0.f, r_delta = 0.f;
-    auto load_tile = [&](int i0) {
-        tile_load<DH, NT>(qr, base, rs, i0, S, tid);
-        tile_load<DH, NT>(gr, gp, (unsigned)(H * DH), i0, S, tid);
-        if (tid < 64 && i0 + tid < S) {
-            r_lse = lse_bh[i0 + tid];
-            r_delta = delta_bh[i0 + tid];
-        }
-    };
-    auto store_tile = [&](int i0, int buf) {
-        tile_store<DH, NT>(qr, smem + buf * 2 * TB, tid);
-        tile_store<DH, NT>(gr, smem + buf * 2 * TB + TB, tid);
-        if (tid < 64) {
-            const bool ok = i0 + tid < S;
-            stats[buf * 128 + tid] = ok ? -(sb * (float)tid + r_lse * LOG2E * inv_c) : -INFINITY;
-            stats[buf * 128 + 64 + tid] = ok ? -r_delta : 0.f;
-        }
-    };
-    load_tile(t0 * 64);
-    store_tile(t0 * 64, 0);
-    if (t0 + 1 < ntiles) load_tile(t0 * 64 + 64);
-    __syncthreads();
-    // One 64-query tile.  DIAG = true: the tile may touch the causal diagonal of this wave's keys
-    // (wave-uniform skips + per-element mask); DIAG = false: every query sees every key of the
-    // workgroup, the body is branch-free.  Only the first two tiles of a workgroup can be diagonal:
-    // keeping them out of the steady-state loop keeps the dK/dV accumulators in one register class
-    // there (with the skips inside the loop hipcc copied all 128 of them AGPR<->VGPR every tile:
-    // 540 v_accvgpr moves per 64 MFMAs; the peeled loop runs the backward 16 % faster).
-    // A hand-pipelined five-phase body (sched_group_barrier) was measured and is not kept: no gain
-    // at dh 128 (the wave is issue-bound: ~480 non-MFMA instructions per 64 MFMAs) and slower at dh 64.
-    auto tile_body = [&](int t, auto diag_tag) {
-        constexpr bool DIAG = decltype(diag_tag)::value;
-        const int i0 = t * 64;
-        const int buf = (t - t0) & 1;
-        const char* Qs = smem + buf * 2 * TB;
-        const char* Gs = Qs + TB;
-        const float* Ls = stats + buf * 128;
-        const float* Dn = Ls + 64;
-#ifndef MGX_ABL_NOSTAGE                   // timing experiment only: results are wrong
-        if (t + 1 < ntiles) store_tile(i0 + 64, buf ^ 1);
-        if (t + 2 < ntiles) load_tile(i0 + 128);
-#endif
-        if (!DIAG || i0 + 63 >= jw0) {                             // wave-uniform
-            const float cj = sb * (float)(j - i0);
-            const bool diag = DIAG && i0 < jw0 + 31;
-            const int di = j - i0 - 4 * h5;                        // masked when row-part < di
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb) {
-                if (DIAG && i0 + 32 * tb + 31 < jw0) continue;     // block entirely above the diagonal
-                f32x16 sc, dp;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 lv = *reinterpret_cast<const f32x4*>(Ls + 32 * tb + 8 * g + 4 * h5);
-                    const f32x4 dn = *reinterpret_cast<const f32x4*>(Dn + 32 * tb + 8 * g + 4 * h5);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        sc[4 * g + k] = cj + lv[k];
-                        dp[4 * g + k] = dn[k];
-                    }
-                }
-#pragma unroll
-                for (int ks = 0; ks < DH / 16; ++ks) {
-                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(Qs + la.row_read(tb, ks)), kf[ks], sc, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(Gs + la.row_read(tb, ks)), vf[ks], dp, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-#ifdef MGX_ABL_NOEXP                     // timing experiment only: results are wrong
-                    float p = sc[r] * c;
-#else
-                    float p = fast_exp2(sc[r] * c);
-#endif
-                    if (DIAG && diag && (32 * tb + (r & 3) + 8 * (r >> 2) < di)) p = 0.f;
-                    sc[r] = p;
-                    dp[r] = p * dp[r] * scale;
-                }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 pf = pack8(sc, 8 * s2);
-                    const bf16x8 dsf = pack8(dp, 8 * s2);
-#pragma unroll
-                    for (int d = 0; d < DH / 32; ++d) {
-                        const bf16x8 gt = lds_read_tr_pair(Gs + la.tr_read(tb, s2, 0, d), Gs + la.tr_read(tb, s2, 1, d));
-                        dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pf, dv[d], 0, 0, 0);
-                        const bf16x8 qt = lds_read_tr_pair(Qs + la.tr_read(tb, s2, 0, d), Qs + la.tr_read(tb, s2, 1, d));
-                        dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, dsf, dk[d], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    };
-    const int tdiag = min(ntiles, t0 + (KB + 63) / 64);            // tiles [t0, tdiag) can touch the diagonal
-    for (int t = t0; t < tdiag; ++t) tile_body(t, std::true_type{});
-    for (int t = tdiag; t < ntiles; ++t) tile_body(t, std::false_type{});
-    if (jok) {
-        bf16_t* op = dqkv + ((long)b * S + j) * rs + (long)h * DH;
-#pragma unroll
-        for (int d = 0; d < DH / 32; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 a, v;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    a[k] = (bf16_t)dk[d][4 * g + k];
-                    v[k] = (bf16_t)dv[d][4 * g + k];
-                }
-                *reinterpret_cast<bf16x4*>(op + (long)H * DH + 32 * d + 8 * g + 4 * h5) = a;
-                *reinterpret_cast<bf16x4*>(op + 2L * H * DH + 32 * d + 8 * g + 4 * h5) = v;
-            }
-    }
-}
-
-template <int DH, int NW>
 int launch_bwd_mfma(const void* dout, const void* qkv, const void* out, const float* lse, const float* slopes,
-                    void* dqkv, float* ws, int B, int S, int H, hipStream_t st) {
-    const float scale = 1.0f / sqrtf((float)DH);
-    const float c = LOG2E * scale;
+                    void* dqkv, float* ws, int B, int S, int H, int dh, hipStream_t st) {
     const int Sp = (S + 63) / 64 * 64;
-    // statistics pre-pass (nl | nd in ws) + the software-pipelined dK/dV kernel (attn_bwd_pipe.hip)
-    const int rc = mgx_attn_bwd_dkv_pipe(dout, qkv, out, lse, slopes, dqkv, ws, B, S, H, DH, st);
+    const int rc = mgx_attn_bwd_dkv_pipe(dout, qkv, out, lse, slopes, dqkv, ws, B, S, H, dh, st);
     if (rc != MGX_OK) return rc;
-    const float* nd = ws + 8L * B * H * Sp;          // nla | nda (16 B per row each) | nd32
-    return mgx_attn_bwd_dq_pipe(dout, qkv, lse, nd, slopes, dqkv, B, S, H, DH, st);
+    const float* nd = ws + 8L * B * H * Sp;          // workspace: nla | nda (16 B per row each) | nd32
+    return mgx_attn_bwd_dq_pipe(dout, qkv, lse, nd, slopes, dqkv, B, S, H, dh, st);
 }
 
 }  // namespace
@@ -507,7 +216,7 @@ int mgx_attn_fwd_mfma(int mode, const void* qkv, const float* slopes, const void
     if (mode == 1) return mgx_rel_fwd_mfma(qkv, E, out, lse, B, S, H, dh, max_seq, st);
     MGX_REQUIRE(mode == 0, MGX_EUNSUPPORTED, "mgx_attn_fwd_mfma: mode %d", mode);
     const float c = LOG2E / sqrtf((float)dh);
-    constexpr int NW = MGX_ATTN_NW;
+    constexpr int NW = 8;                                // waves (x 32 queries) per workgroup
     dim3 grid(H, B, (S + 32 * NW - 1) / (32 * NW));
     if (dh == 64)
         hipLaunchKernelGGL((attn_fwd_mfma_kernel<64, NW>), grid, dim3(64 * NW), 0, st, (const bf16_t*)qkv, slopes,
@@ -524,6 +233,5 @@ int mgx_attn_bwd_mfma(int mode, const void* dout, const void* qkv, const void* o
                       int dh, int max_seq, hipStream_t st) {
     if (mode == 1) return mgx_rel_bwd_mfma(dout, qkv, out, lse, E, dqkv, dE, delta, B, S, H, dh, max_seq, st);
     MGX_REQUIRE(mode == 0, MGX_EUNSUPPORTED, "mgx_attn_bwd_mfma: mode %d", mode);
-    if (dh == 64) return launch_bwd_mfma<64, MGX_ATTN_NW>(dout, qkv, out, lse, slopes, dqkv, delta, B, S, H, st);
-    return launch_bwd_mfma<128, MGX_ATTN_NW>(dout, qkv, out, lse, slopes, dqkv, delta, B, S, H, st);
+    return launch_bwd_mfma(dout, qkv, out, lse, slopes, dqkv, delta, B, S, H, dh, st);
 }

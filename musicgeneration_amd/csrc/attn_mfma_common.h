@@ -8,18 +8,6 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float RESCALE_LOG2 = 8.0f;
-#ifndef MGX_DQ_OCC
-#define MGX_DQ_OCC 2             // waves per SIMD the dQ kernel is compiled for
-#endif
-#ifndef MGX_DKV_OCC
-#define MGX_DKV_OCC (DH == 128 ? NW / 4 : 2)
-#endif
-#ifndef MGX_DKV_NW
-#define MGX_DKV_NW 4             // dK/dV kernel: 4 waves, one per SIMD, 512 registers each at dh=128
-#endif
-#ifndef MGX_ATTN_NW
-#define MGX_ATTN_NW 8            // waves (x 32 rows) per workgroup
-#endif
 
 template <int DH>
 struct Img {

@@ -21,12 +21,8 @@
 
 namespace {
 
-#ifndef MGX_REL_NW
-#define MGX_REL_NW 4
-#endif
-#ifndef MGX_REL_DE_NW
-#define MGX_REL_DE_NW 2          // dE kernel: 64 distances per band x 2 query-half groups = 4 waves; bands paired
-#endif
+constexpr int REL_NW = 4;        // waves (x 32 rows) per workgroup
+constexpr int REL_DE_NW = 2;     // dE kernel: 64 distances per band x 2 query-half groups = 4 waves; bands paired
 constexpr int SKS = 68;          // ring row stride in floats (272 B: 16-byte reads of 16 consecutive lanes spread over all banks)
 
 // ---- the skew ring (query-on-lane kernels) ----------------------------------------------------
@@ -700,10 +696,8 @@ __device__ __forceinline__ void rel_de_band(
             const char* Gs = Qs + TB;
             const float* Ls = stats + buf * 128;
             const float* Dn = Ls + 64;
-#ifndef REL_ABL_NOSTAGE
             if (t + 1 < ntiles) store_tile(i0 + 64, buf ^ 1);
             if (t + 2 < ntiles) load_tile(i0 + 128);
-#endif
             if (rw0 < S) {                                     // wave-uniform
                 {
                     const int JB = i0 + 32 * tb - rw0;         // key of (query block start, distance rw0)
@@ -730,13 +724,9 @@ __device__ __forceinline__ void rel_de_band(
                             sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], KVL ? lds_read16(Kb + la.row_read(hb, ks)) : kb[ks], sb, 0, 0, 0);
                             if (JB > 0) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], KVL ? lds_read16(Ka + la.row_read(ha, ks)) : ka[ks], sa, 0, 0, 0);
                         }
-#ifdef REL_ABL_NOSKEW
-                        sc = sa + sb;
-#else
                         band_put(skew, sa, 0, l31, h5);
                         band_put(skew, sb, 1, l31, h5);
                         band_get(skew, sc, l31, h5);
-#endif
                     }
                     {
                         f32x16 pa, pb;
@@ -747,13 +737,9 @@ __device__ __forceinline__ void rel_de_band(
                             pb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[ks], KVL ? lds_read16(Kb + TB + la.row_read(hb, ks)) : vb[ks], pb, 0, 0, 0);
                             if (JB > 0) pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[ks], KVL ? lds_read16(Ka + TB + la.row_read(ha, ks)) : va[ks], pa, 0, 0, 0);
                         }
-#ifdef REL_ABL_NOSKEW
-                        dp = pa + pb;
-#else
                         band_put(skew, pa, 0, l31, h5);
                         band_put(skew, pb, 1, l31, h5);
                         band_get(skew, dp, l31, h5);
-#endif
                     }
                     if (!KVL) load_kv(JB + 64);                // this wave's next block (one tile further)
 #pragma unroll
@@ -772,11 +758,7 @@ __device__ __forceinline__ void rel_de_band(
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int il = 8 * (e >> 2) + 4 * h5 + (e & 3);
-#ifdef REL_ABL_NOEXP
-                        float p = sc[e] * c;
-#else
                         float p = fast_exp2(sc[e] * c);
-#endif
                         if (JB + il - l31 < 0) p = 0.f;        // key index below 0 (distance beyond the query)
                         sc[e] = p * dp[e] * scale;
                     }
@@ -855,7 +837,7 @@ constexpr size_t rel_fwd_smem(int nw) { return (size_t)4 * Img<DH>::TILE_BYTES +
 int mgx_rel_fwd_mfma(const void* qkv, const void* E, void* out, float* lse, int B, int S, int H, int dh, int max_seq,
                      hipStream_t st) {
     const float c = LOG2E / sqrtf((float)dh);
-    constexpr int NW = MGX_REL_NW;
+    constexpr int NW = REL_NW;
     dim3 grid(H, B, (S + 32 * NW - 1) / (32 * NW));
     allow_smem(rel_fwd_mfma_kernel<64, NW>, rel_fwd_smem<64>(NW));
     allow_smem(rel_fwd_mfma_kernel<128, NW>, rel_fwd_smem<128>(NW));
@@ -877,7 +859,7 @@ int launch_rel_bwd(const void* dout, const void* qkv, const void* out, const flo
                    float* dE, float* delta, int B, int S, int H, int max_seq, hipStream_t st) {
     const float scale = 1.0f / sqrtf((float)DH);
     const float c = LOG2E * scale;
-    constexpr int NW = MGX_REL_NW;
+    constexpr int NW = REL_NW;
     const int M = max_seq, Mp = (M + 31) / 32 * 32;
     // the dE buffer (fp32 [H,M,DH]) holds the transposed bf16 copy of E (H*DH*Mp*2 bytes <= its size
     // since Mp <= 2M) until the dE kernel, which runs last, overwrites it
@@ -901,7 +883,7 @@ int launch_rel_bwd(const void* dout, const void* qkv, const void* out, const flo
                        (const bf16_t*)dout, (const bf16_t*)qkv, lse, delta, (const bf16_t*)E, (const bf16_t*)ErT,
                        (bf16_t*)dqkv, S, H, M, Mp, c, scale);
     MGX_CHECK_LAUNCH("rel_bwd_dq_mfma");
-    constexpr int NWE = MGX_REL_DE_NW;
+    constexpr int NWE = REL_DE_NW;
     const int nbands = (M + 32 * NWE - 1) / (32 * NWE);
     const size_t de_smem = (size_t)(DH == 64 ? 10 : 4) * Img<DH>::TILE_BYTES + 4 * 64 * sizeof(float) + (size_t)2 * NWE * 32 * BKS * sizeof(float);
     dim3 gride(H, (nbands + 1) / 2);

@@ -177,9 +177,6 @@ __device__ __forceinline__ float dpp_add(float v, const int ctrl_tag) {
     return v + __int_as_float(y);
 }
 
-#ifndef MGX_DEC_U
-#define MGX_DEC_U 4
-#endif
 template <int DH, int NW, int R>
 __global__ __launch_bounds__(NW * 64, 4) void decode_attn_bf16_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
@@ -189,7 +186,7 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attn_bf16_kernel(
     // projection output [B,R,3,H,DH]; this workgroup also files those K/V rows into the caches.
     constexpr int LPR = DH / 8;          // lanes per key row: 16 (dh 128) or 8 (dh 64)
     constexpr int RPL = 64 / LPR;        // key rows per wave-load
-    constexpr int U = MGX_DEC_U;         // wave-loads per chunk
+    constexpr int U = 4;                 // wave-loads per chunk
     constexpr float NEG = -1.0e30f;
     constexpr float LOG2E = 1.4426950408889634f;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [NW][R][DH + 2]

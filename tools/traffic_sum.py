@@ -18,8 +18,8 @@ for name, tagf, tagw, pat, algo, also in (
         ("attn_fwd_mfma_kernel<128,8> B16 S2048 H8", "attn_fetch", "attn_write", "attn_fwd_mfma_kernel",
          16 * 2048 * 3072 * 2 + 16 * 2048 * 1024 * 2 + 16 * 8 * 2048 * 4, None),
         ("attn_bwd dkv+dq+delta <128> B16 S2048 H8 (per backward = per dkv launch)", "attnb_fetch", "attnb_write",
-         "attn_bwd_dkv_mfma_kernel", 2 * 16 * 2048 * 3072 * 2 + 2 * 16 * 2048 * 1024 * 2 + 16 * 8 * 2048 * 4,
-         ("attn_bwd_dq_mfma_kernel", "attn_delta")),
+         "attn_bwd_dkv_pipe_kernel", 2 * 16 * 2048 * 3072 * 2 + 2 * 16 * 2048 * 1024 * 2 + 16 * 8 * 2048 * 4,
+         ("attn_bwd_dq_pipe_kernel", "attn_bwd_stats_kernel")),
         ("gemm_tn_kernel + splitk_reduce, mean of dw2/dw1/dwp/dwqkv at T=32768 d=1024 ff=4096", "tn_fetch", "tn_write",
          "gemm_tn_kernel", tn_algo, ("splitk_reduce",)),
         ("gemm_nt_kernel<gelu,dropout> mlp1 T=32768 d=1024 ff=4096", "tn_fetch", "tn_write", "gemm_nt_kernel",
