@@ -257,6 +257,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
             const int n = nb + 16 * j + 4 * g4;
             if (g.bias && n < g.N) bv[j] = *reinterpret_cast<const f32x4*>(g.bias + n);
         }
+        // the second operand of the epilogue (residual / pre-activation) for the wave's whole 256 x 32 slice, requested
+        // up front with clamped addresses (no branch: the 8 loads leave back to back and one round trip is exposed per
+        // slice instead of one per 16-row block), 16 bytes per lane in the layout of the stores below and turned back
+        // into the accumulator layout by the same 16-lane-row swap
+        uint2 side[2][4][2];
+        const bool has_side = EPI == EPI_DACT || (EPI == EPI_PLAIN && g.res);
+        if (has_side) {
+            const bf16_t* sp = EPI == EPI_DACT ? g.pre : g.res;
+            const int nc = min(nb + nsw, g.N - 8);
+            uint4 raw[2][4];
+#pragma unroll
+            for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int mc = min(m0 + 128 * qa + 64 * wr + 16 * i + l15, g.M - 1);
+                    raw[qa][i] = *reinterpret_cast<const uint4*>(sp + (long)mc * g.ldc + nc);
+                }
+#pragma unroll
+            for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    auto s0 = __builtin_amdgcn_permlane16_swap(raw[qa][i].x, raw[qa][i].z, false, false);
+                    auto s1 = __builtin_amdgcn_permlane16_swap(raw[qa][i].y, raw[qa][i].w, false, false);
+                    side[qa][i][0] = make_uint2(s0[0], s1[0]);
+                    side[qa][i][1] = make_uint2(s0[1], s1[1]);
+                }
+        }
         float csum[2][4];
         if (EPI == EPI_DACT) {
 #pragma unroll
@@ -280,14 +307,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
                 if (EPI == EPI_PLAIN && g.res) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const int n = nb + 16 * j + 4 * g4;
-                        if (n < g.N) {
-                            const uint2 rr = *reinterpret_cast<const uint2*>(g.res + (long)mc * g.ldc + n);
-                            v[j][0] += bf_lo(rr.x);
-                            v[j][1] += bf_hi(rr.x);
-                            v[j][2] += bf_lo(rr.y);
-                            v[j][3] += bf_hi(rr.y);
-                        }
+                        const uint2 rr = side[qa][i][j];         // columns past N: some real value, never stored
+                        v[j][0] += bf_lo(rr.x);
+                        v[j][1] += bf_hi(rr.x);
+                        v[j][2] += bf_lo(rr.y);
+                        v[j][3] += bf_hi(rr.y);
                     }
                 }
                 if (EPI == EPI_DACT) {
@@ -295,8 +319,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int n = nb + 16 * j + 4 * g4;
-                        uint2 pp = make_uint2(0u, 0u);
-                        if (n < g.N) pp = *reinterpret_cast<const uint2*>(g.pre + (long)mc * g.ldc + n);
+                        const uint2 pp = side[qa][i][j];
                         const float x[4] = {bf_lo(pp.x), bf_hi(pp.x), bf_lo(pp.y), bf_hi(pp.y)};
 #pragma unroll
                         for (int r = 0; r < 4; r += 2) {
