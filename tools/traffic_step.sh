@@ -15,8 +15,8 @@ run step_fetch FETCH_SIZE $STEP && \
 run step_write WRITE_SIZE $STEP && \
 run dec_fetch FETCH_SIZE $R/tools/decode_one.py 2112 5 && \
 run dec_write WRITE_SIZE $R/tools/decode_one.py 2112 5 && \
-python3 $R/tools/traffic_step_sum.py $R/gpurun_out > $R/gpurun_out/r02_traffic_pmc.json && \
+python3 $R/tools/traffic_step_sum.py $R/gpurun_out > $R/gpurun_out/r02b_traffic_pmc.json && \
 for t in step_fetch step_write dec_fetch dec_write; do
   f=$(find $R/gpurun_out/tr2_$t -name '*counter_collection.csv' | sort | sed -n 1p)
-  python3 $R/tools/pmc_compact.py $f > $R/gpurun_out/r02_traffic_${t}_per_kernel.csv
-done && cat $R/gpurun_out/r02_traffic_pmc.json
+  python3 $R/tools/pmc_compact.py $f > $R/gpurun_out/r02b_traffic_${t}_per_kernel.csv
+done && cat $R/gpurun_out/r02b_traffic_pmc.json

@@ -28,7 +28,7 @@ for key, name, tagf, tagw, pat, algo, also in (
          "step_fetch", "step_write", "gemm_tn_kernel", tn_algo, ("splitk_reduce",)),
         ("alibi_attn_fwd", "attn_fwd_mfma_kernel<128,8> B16 S2048 H8", "step_fetch", "step_write", "attn_fwd_mfma_kernel",
          16 * 2048 * 3072 * 2 + 16 * 2048 * 1024 * 2 + 16 * 8 * 2048 * 4, None),
-        ("alibi_attn_bwd", "attn_bwd dkv+dq+delta <128> B16 S2048 H8 (per backward = per dkv launch)", "step_fetch",
+        ("alibi_attn_bwd", "attn_bwd stats + dkv_pipe + dq_pipe <128> B16 S2048 H8 (per backward = per dkv launch)", "step_fetch",
          "step_write", "attn_bwd_dkv_pipe_kernel", 2 * 16 * 2048 * 3072 * 2 + 2 * 16 * 2048 * 1024 * 2 + 16 * 8 * 2048 * 4,
          ("attn_bwd_dq_pipe_kernel", "attn_bwd_stats_kernel")),
         ("decode_attn", "decode_attn_bf16_kernel B64 H8 dh128 R3 ctx2112", "dec_fetch", "dec_write", "decode_attn",
