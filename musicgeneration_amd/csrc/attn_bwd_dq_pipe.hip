@@ -362,6 +362,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pipe_kernel(DqArgs g) {
 
         // ---- item done.  The last MFMAs must have written dQ before it is read back (nothing tells the compiler).
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        // The next item's resident rows (requested a unit ago, younger than every tile request in flight) are waited
+        // for HERE, before the epilogue's stores are issued: after them a vmcnt(0) would also wait for the stores'
+        // acknowledgements.  The counted tile waits of the next item stay valid with stores outstanding: loads
+        // retire in order among themselves, stores only make the count conservative.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PIPE_FENCE();
         {
             // dQ^T has the query on the lane and dh down the registers: each wave turns its 32 queries x 64 columns
@@ -407,9 +412,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pipe_kernel(DqArgs g) {
         c_bh = n_bh;
         c_qb = n_qb;
         sfor<16 * DB>([&](auto rt) { agpr_zero<Cfg::R_DQ + decltype(rt)::value>(); });
-        // the next item's Q / dO rows (requested a unit ago); every tile requested before them has landed as well,
-        // and the first of them was complete in every wave at the last tile top
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PIPE_FENCE();
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-fetched tail tiles

@@ -441,6 +441,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pipe_kernel(DkvArgs g) {
         // ---- item done.  The last MFMAs must have written dK / dV before they are read back (16 passes; nothing
         // tells the compiler about the dependency).
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        // The next item's resident rows (requested a unit ago, younger than every tile request in flight) are waited
+        // for HERE, before the epilogue's stores are issued: after them a vmcnt(0) would also wait for the stores'
+        // acknowledgements.  The counted tile waits of the next item stay valid with stores outstanding: loads
+        // retire in order among themselves, stores only make the count conservative.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PIPE_FENCE();
         {
             // dK^T / dV^T have the key on the lane and dh down the registers: written out directly, every store
@@ -489,9 +494,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pipe_kernel(DkvArgs g) {
         c_bh = n_bh;
         c_kb = n_kb;
         sfor<32 * DB>([&](auto rt) { agpr_zero<decltype(rt)::value>(); });
-        // the next item's K / V (requested a unit ago); every tile requested before them has landed as well, and the
-        // first of them was complete in every wave at the last tile top
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PIPE_FENCE();
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-fetched tail tiles
