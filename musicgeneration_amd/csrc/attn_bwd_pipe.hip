@@ -396,7 +396,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pipe_kernel(DkvArgs g) {
             // MFMAs (with the dO^T fragments of unit u+1 between them)
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NGX < 15 ? NGX : 15) : "memory");   // dO^T fragments of unit u
             PIPE_FENCE();
-            const bf16x8 pb[2] = {words_to_frag(pf[0], pf[1], pf[2], pf[3]), words_to_frag(pf[4], pf[5], pf[6], pf[7])};
+            bf16x8 pb[2] = {words_to_frag(pf[0], pf[1], pf[2], pf[3]), words_to_frag(pf[4], pf[5], pf[6], pf[7])};
+            pin_frags(pb[0], pb[1]);                      // VALU write of P -> MFMA read
             bf16x8 db[2];
             PIPE_FENCE();
             sfor<Cfg::NG_Y>([&](auto gt) {
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pipe_kernel(DkvArgs g) {
                     if constexpr (f == HF) {
                         db[0] = words_to_frag(dsf[0], dsf[1], dsf[2], dsf[3]);
                         db[1] = words_to_frag(dsf[4], dsf[5], dsf[6], dsf[7]);
-                        asm volatile("s_nop 1" ::: "memory");     // VALU write of dS -> MFMA read
+                        pin_frags(db[0], db[1]);                  // VALU write of dS -> MFMA read
                     }
                     // Q^T fragment f - HF was read in gap f - HF; 2 (HF - 1) reads have been issued since
                     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (HF - 1)) : "memory");

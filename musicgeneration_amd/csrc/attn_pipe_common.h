@@ -69,6 +69,10 @@ __device__ __forceinline__ float agpr_get() {
     asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(v) : "n"(R));
     return v;
 }
+template <int R>
+__device__ __forceinline__ void agpr_put(float v) {
+    asm volatile("v_accvgpr_write_b32 a[%0], %1" ::"n"(R), "v"(v));
+}
 template <int R0>
 __device__ __forceinline__ void global_b128_to_agpr(const void* p) {
     asm volatile("global_load_dwordx4 a[%1:%2], %0, off" ::"v"(p), "n"(R0), "n"(R0 + 3) : "memory");
@@ -77,6 +81,11 @@ __device__ __forceinline__ void global_b128_to_agpr(const void* p) {
 __device__ __forceinline__ float fma_np(float a, float b, float c) {
     float r;
     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float add_np(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 __device__ __forceinline__ float mul_np(float a, float b) {
@@ -104,6 +113,13 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 __device__ __forceinline__ bf16x8 words_to_frag(unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
     return __builtin_bit_cast(bf16x8, u32x4{w0, w1, w2, w3});
+}
+
+// Both halves of a freshly packed MFMA operand pinned in registers HERE, followed by the wait states a VALU write
+// needs before an MFMA reads the register.  Without the "+v" operands hipcc sinks the v_cvt_pk of the second half to
+// right before its first use -- an inline-asm MFMA the hazard recogniser does not see, so it read the old contents.
+__device__ __forceinline__ void pin_frags(bf16x8& f0, bf16x8& f1) {
+    asm volatile("s_nop 1" : "+v"(f0), "+v"(f1)::"memory");
 }
 
 }  // namespace

@@ -1,63 +1,74 @@
-// bf16 MFMA flash-attention backward for gfx950, dQ kernel: the mirror image of attn_bwd_pipe.hip (same pipeline,
-// see the notes there).  Autograd of SimpleAttention.multihead_attn (model_baseline/alibi_unified.py:40-54).
+// LAB, not part of libmgx: the forward on the backward kernels' one-wave-per-SIMD pipeline.  Correct (passes the
+// attention tests when wired into attn_mfma.hip), but NOT faster than attn_fwd_mfma_kernel at B16 S2048 H8 dh128:
+// 374 us against 215 us as written, 250 us without the O rescale loop, 196 us with the rescale branch removed
+// altogether (wrong results).  With ALiBi the row maximum of the heads with large slopes grows by 32*slope*log2(e)
+// > 2^8 per 32-key unit, so the deferred rescale fires every unit for heads 0-1, and O lives in AGPRs here (64
+// read / multiply / write triples per rescale).  Walking the keys from the diagonal backwards would make the
+// rescale rare, but the 196 us floor (45 % MFMA busy) is only 9 % under the shipped kernel.  To build it: copy into
+// musicgeneration_amd/csrc/ and call mgx_attn_fwd_pipe from mgx_attn_fwd_mfma.
+// bf16 MFMA flash-attention forward for gfx950 on the pipeline of attn_bwd_dq_pipe.hip (see the notes there and in
+// attn_bwd_pipe.hip).  SimpleAttention.multihead_attn (model_baseline/alibi_unified.py:40-54): causal softmax of
+// q.k^T / sqrt(dh) + slope_h (j - i), times v; nothing S x S reaches HBM, the [H,S,S] mask buffer
+// (alibi_unified.py:26-31) does not exist.
 //
-// One wave per SIMD (4 waves, 32 queries each: this lane's query row of Q and dO and the 32 x dh dQ accumulators stay
-// in registers); persistent workgroups walk (batch, head, 128-query block) items, late (long) and early (short) query
-// blocks paired; K / V tiles of 64 keys stream through the 4-slot LDS-DMA ring across item boundaries.  Per unit u of
-// 32 keys and wave:
-//     A(u)  S^T = K.Q^T + bias - lse, dP^T = V.dO^T - delta     2*(dh/16 + 1) MFMAs: bias, lse and delta enter as one
-//                                                                extra k-step whose operands are constants of the item
-//     B(u)  P^T = exp2(c S^T + cu), dS^T = P^T * dP^T           plain fp32 VALU
-//     C(u)  dQ^T += K^T.dS^T                                     2*dh/32 MFMAs (dS^T straight from the accumulators)
-// X(u) = A(u+1) with B(u) and the K / V row fragments of unit u+2 between the MFMAs; Y(u) = C(u) with the K^T
-// fragments of unit u+1 between them.
-#include "attn_pipe_common.h"
+// One wave per SIMD (4 waves, 32 queries each: the lane's query row of Q and the 32 x dh O accumulators stay in
+// hand-allocated AGPRs); persistent workgroups walk (batch, head, 128-query block) items, late (long) and early
+// (short) query blocks paired; K / V tiles of 64 keys stream through a 4-slot LDS-DMA ring across item boundaries.
+// Per unit u of 32 keys and wave:
+//     A(u)  S^T = K.Q^T + bias            dh/16 + 1 MFMAs: the bias enters as one extra k-step whose operands are
+//                                          constants of the item (key part x ones + ones x query part)
+//     B(u)  P^T = exp2(c S^T + cu - m)    online softmax with the deferred rescale of attn_mfma.hip: the running
+//                                          maximum m is only raised when a row's maximum grew by more than 2^8
+//     C(u)  O^T += V^T.P^T                 2*dh/32 MFMAs (P^T straight from the accumulators)
+// X(u) = A(u+1) with the exponentials of unit u and the K row fragments of unit u+2 between the MFMAs; Y(u) = C(u)
+// with the V^T fragments of unit u+1 and the mask + row maxima of unit u+1 between them; the (rare, wave-uniform)
+// rescale of O sits between Y(u) and X(u+1).
+#include "../../musicgeneration_amd/csrc/attn_pipe_common.h"
 
 namespace {
 
-// the lgkmcnt field is 4 bits
-constexpr int lgkm_cap(int n) { return n < 15 ? n : 15; }
+constexpr int fwd_lgkm_cap(int n) { return n < 15 ? n : 15; }     // the lgkmcnt field is 4 bits
 
 template <int DH>
-struct DqCfg {
+struct FwdCfg {
     static constexpr int NB = 4;                       // LDS ring slots (one 64-key tile each)
     static constexpr int UB = 32 * DH * 2;             // bytes of one 32 x dh bf16 image (a unit)
     static constexpr int TB = 2 * UB;                  // a 64-row tile of K or V
     static constexpr int SLOT = 2 * TB;
     static constexpr int VM_PER_TILE = 4 * (DH / 64);  // LDS-DMA instructions per wave and tile
+    static constexpr int PPU = VM_PER_TILE / 2;        // ... issued per unit, at the odd gaps of X
     static constexpr int KS = DH / 16, DB = DH / 32;
-    static constexpr int NG_X = 2 * KS + 2;            // MFMAs of stage A (S^T and dP^T chains, statistics step last)
+    static constexpr int NG_X = KS + 1;                // MFMAs of stage A (the bias step last)
     static constexpr int NG_Y = 2 * DB;                // MFMAs of stage C
-    static constexpr int EPG = DH == 128 ? 1 : 2;      // elements of P per gap of X
+    static constexpr int EPG = 16 / KS;                // elements of P per gap of X
     // AGPR map
-    static constexpr int R_DQ = 0, R_QF = 16 * DB, R_GF = R_QF + 4 * KS, R_TK = R_GF + 4 * KS;
-    static constexpr int R_END = R_TK + 4 * NG_Y;      // 160 at dh 128
+    static constexpr int R_O = 0, R_QF = 16 * DB, R_TV = R_QF + 4 * KS;
+    static constexpr int R_END = R_TV + 4 * NG_Y;      // 128 at dh 128
 };
 
-struct DqArgs {
-    const bf16_t* dout;
+struct FwdArgs {
     const bf16_t* qkv;
-    const float* lse;
-    const float* nd32;  // -delta, rows padded to Sp
     const float* slopes;
-    bf16_t* dqkv;
+    bf16_t* out;
+    float* lse;
     int B, S, Sp, H;
-    float c, scale;
+    float c;            // scale * log2(e)
     int nqb, np;        // 128-query blocks per (b,h); pairs of them
     int nwork;          // B*H*np pairs in all
 };
 
 template <int DH>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_pipe_kernel(DqArgs g) {
-    using Cfg = DqCfg<DH>;
+__global__ __launch_bounds__(256, 1) void attn_fwd_pipe_kernel(FwdArgs g) {
+    using Cfg = FwdCfg<DH>;
     constexpr int NB = Cfg::NB, UB = Cfg::UB, TB = Cfg::TB, SLOT = Cfg::SLOT, G8 = Img<DH>::G8;
-    constexpr int KS = Cfg::KS, DB = Cfg::DB, NGX = Cfg::NG_X, NGY = Cfg::NG_Y, VM = Cfg::VM_PER_TILE;
+    constexpr int KS = Cfg::KS, DB = Cfg::DB, NGX = Cfg::NG_X, NGY = Cfg::NG_Y, VM = Cfg::VM_PER_TILE, PPU = Cfg::PPU;
     static_assert(Cfg::R_END <= 256, "AGPR map");
-    static_assert(2 * VM <= NGX, "one LDS-DMA piece per odd gap of X");
+    static_assert(2 * PPU - 1 < NGX, "one LDS-DMA piece per odd gap of X");
+    static_assert(NGY >= 4, "mask + row maxima of the next unit start at gap 3 of Y");
     constexpr int EPI = NB * SLOT;                       // 4 KiB per wave: transposition buffer of the item epilogue
     __shared__ __attribute__((aligned(1024))) char smem[NB * SLOT + 4 * 4096];
     // the AGPRs named in the asm below, made known to the compiler's resource accounting (it allocates none itself)
-    asm volatile("" ::: "a0", "a127", "a159");
+    asm volatile("" ::: "a0", "a63", "a127");
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h5 = lane >> 5;
@@ -149,70 +160,52 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pipe_kernel(DqArgs g) {
 
     // ---- consumer state
     const unsigned lds0 = lds_addr32(smem);
-    bf16x8 rk[KS], rv[KS];           // row fragments of K / V (A operands of S^T / dP^T)
-    // statistics step.  S^T[j][i] += ka[j][.] . bq[.][i]:  ka = (t_j split in three, 1, 1, 1, 0, 0) with
-    // t_j = slope*log2e/c * (j mod 32), bq = (1, 1, 1, x_i split in three, 0, 0) with x_i = -(slope*log2e/c * (i - i0)
-    // + lse_i*log2e/c), i0 the wave's first query; dP^T[j][i] += ones[j][.] . bg[.][i], bg = (-delta_i split in three).
-    // Only the lanes of the first half carry them (k = 0..7); the second half (k = 8..15) is zero.
-    bf16x8 ka, ones, bq, bg;
+    bf16x8 rk[KS];                   // row fragments of K (A operand of S^T)
+    // bias step.  S^T[j][i] += ka[j][.] . bq[.][i]:  ka = (t_j split in three, 1, 1, 1, 0, 0) with
+    // t_j = slope*log2e/c * (j mod 32), bq = (1, 1, 1, x_i split in three, 0, 0) with x_i = -slope*log2e/c * (i - i0),
+    // i0 the wave's first query.  Only the lanes of the first half carry them (k = 0..7); the second half is zero.
+    bf16x8 ka, bq;
     auto split3v = [&](float x, bf16_t& hi, bf16_t& mid, bf16_t& lo) {
         hi = (bf16_t)x;
         const float r1 = x - (float)hi;
         mid = (bf16_t)r1;
         lo = (bf16_t)(r1 - (float)mid);
     };
-#pragma unroll
-    for (int k = 0; k < 8; ++k) ones[k] = (bf16_t)((h5 == 0 && k < 3) ? 1.0f : 0.0f);
 
-    // row fragment fg of the unit at byte `ub`: fg even: K rows (S^T chain), odd: V rows (dP^T chain); k-step fg >> 1
-    auto read_row = [&](auto gt, unsigned ub) {
-        constexpr int fg = decltype(gt)::value, ks = fg >> 1;
-        if constexpr (ks < KS) {
-            const unsigned a = ub + ((ks & 1) ? la.row1 : la.row0);
-            if constexpr (fg & 1)
-                rv[ks] = lds_b128<TB + 512 * (ks >> 1)>(a);
-            else
-                rk[ks] = lds_b128<512 * (ks >> 1)>(a);
-        }
+    // K row fragment ks of the unit at byte `ub`
+    auto read_row = [&](auto kt, unsigned ub) {
+        constexpr int ks = decltype(kt)::value;
+        if constexpr (ks < KS) rk[ks] = lds_b128<512 * (ks >> 1)>(ub + ((ks & 1) ? la.row1 : la.row0));
     };
-    // transposed fragment f of stage C of the unit at byte `ub`: K^T -> a[R_TK + 4 f ..]; (s2, d) = (f / DB, f % DB)
+    // transposed fragment f of stage C of the unit at byte `ub`: V^T -> a[R_TV + 4 f ..]; (s2, d) = (f / DB, f % DB)
     auto read_tr = [&](auto ft, unsigned ub) {
         constexpr int f = decltype(ft)::value;
         constexpr int d = f % DB, s2 = f / DB;
-        constexpr int o0 = G8 * (2 * s2) + 512 * d, o1 = o0 + G8;
-        lds_tr128_agpr<Cfg::R_TK + 4 * f, o0, o1>(ub + la.tr0, ub + la.tr1);
+        constexpr int o0 = TB + G8 * (2 * s2) + 512 * d, o1 = o0 + G8;
+        lds_tr128_agpr<Cfg::R_TV + 4 * f, o0, o1>(ub + la.tr0, ub + la.tr1);
     };
-    // stage A: S^T and dP^T chains, alternating (gap index fg: even = S^T, odd = dP^T)
-    auto mfma_a_step = [&](auto gt, f32x16& sc, f32x16& dp) {
-        constexpr int fg = decltype(gt)::value, ks = fg >> 1;
-        if constexpr (fg == 0)
+    // stage A: the S^T chain, bias step last
+    auto mfma_a_step = [&](auto gt, f32x16& sc) {
+        constexpr int ks = decltype(gt)::value;
+        if constexpr (ks == 0)
             mfma_s0<Cfg::R_QF>(sc, rk[0]);
-        else if constexpr (fg == 1)
-            mfma_s0<Cfg::R_GF>(dp, rv[0]);
-        else if constexpr (ks == KS) {
-            if constexpr (fg & 1)
-                mfma_sv(dp, ones, bg);
-            else
-                mfma_sv(sc, ka, bq);
-        } else if constexpr (fg & 1)
-            mfma_s<Cfg::R_GF + 4 * ks>(dp, rv[ks]);
+        else if constexpr (ks == KS)
+            mfma_sv(sc, ka, bq);
         else
             mfma_s<Cfg::R_QF + 4 * ks>(sc, rk[ks]);
     };
     auto load_q = [&](int bh, int qb) {
-        // this lane's query row of Q and dO straight into AGPRs; queries past the end read row S-1 (not stored)
+        // this lane's query row straight into AGPRs; queries past the end read row S-1 (not stored)
         const int b = bh / H, h = bh - b * H;
         const long ir = min(qb * 128 + 32 * w + l31, S - 1);
         const bf16_t* qp = g.qkv + ((long)b * S + ir) * rs + (long)h * DH + 8 * h5;
-        const bf16_t* gp = g.dout + (((long)b * S + ir) * H + h) * DH + 8 * h5;
         sfor<KS>([&](auto kt) {
             constexpr int ks = decltype(kt)::value;
             global_b128_to_agpr<Cfg::R_QF + 4 * ks>(qp + ks * 16);
-            global_b128_to_agpr<Cfg::R_GF + 4 * ks>(gp + ks * 16);
         });
     };
 
-    // ---- start: first item, its Q / dO rows, three tiles in flight
+    // ---- start: first item, its Q rows, three tiles in flight
     int c_n, c_bh = 0, c_qb = 0;
     c_n = next_item(-1, c_bh, c_qb);
     if (c_n >= nseq) return;                             // (uniform) nothing to do for this workgroup
@@ -224,14 +217,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pipe_kernel(DqArgs g) {
     produce();
     produce();
     produce();
-    sfor<16 * DB>([&](auto rt) { agpr_zero<Cfg::R_DQ + decltype(rt)::value>(); });
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * VM) : "memory");      // Q, dO rows and the first tile
+    sfor<16 * DB>([&](auto rt) { agpr_zero<Cfg::R_O + decltype(rt)::value>(); });
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * VM) : "memory");      // Q rows and the first tile
     PIPE_FENCE();
     __builtin_amdgcn_s_barrier();
     PIPE_FENCE();
 
     int slot_c = 0;                                      // slot of the tile being consumed
-    f32x16 scA, dpA, scB, dpB;
+    f32x16 scA, scB;
     while (true) {
         // ================= one item: query block c_qb of (b, h) = c_bh
         const int b = c_bh / H, h = c_bh - b * H;
@@ -242,64 +235,99 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pipe_kernel(DqArgs g) {
         const int ntiles = item_tiles(c_qb);
         const int umask = 4 * c_qb;                      // units >= umask can touch the causal diagonal
         float cu = -csb * (float)i0w;                    // bias of the unit's first key against the wave's first query
+        float m = -INFINITY, l = 0.f;                    // running maximum (log2 units, bias included) and sum
+        float cum = 0.f;                                 // cu - m of the unit whose P is formed next
         {
-            const int ic = min(i, S - 1);
-            const float x = -(csb * (float)l31 + g.lse[((long)b * H + h) * S + ic] * LOG2E) * inv_c;
-            const float nd = g.nd32[((long)b * H + h) * Sp + ic];
+            const float x = -(csb * (float)l31) * inv_c;
             const float tj = csb * inv_c * (float)l31;
-            bf16_t a0, a1, a2, b0, b1, b2, c0, c1, c2;
+            bf16_t a0, a1, a2, b0, b1, b2;
             split3v(tj, a0, a1, a2);
             split3v(x, b0, b1, b2);
-            split3v(nd, c0, c1, c2);
             const bf16_t one = (bf16_t)1.0f, z = (bf16_t)0.0f;
             if (h5 == 0) {
                 ka = bf16x8{a0, a1, a2, one, one, one, z, z};
                 bq = bf16x8{one, one, one, b0, b1, b2, z, z};
-                bg = bf16x8{c0, c1, c2, z, z, z, z, z};
             } else {
-                ka = bq = bg = bf16x8{z, z, z, z, z, z, z, z};
+                ka = bq = bf16x8{z, z, z, z, z, z, z, z};
             }
         }
         int n_bh = 0, n_qb = 0;
         const int n_n = next_item(c_n, n_bh, n_qb);
+
+        // causal mask of unit u on the raw scores, then this lane's maximum over its 16 keys
+        auto mask_max = [&](f32x16& sc, int u) -> float {
+            if (u >= umask) {                            // wave-uniform, at most 4 units per item
+                const int di = i - 32 * u - 4 * h5;      // key row part > di  <=>  key after query
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if ((e & 3) + 8 * (e >> 2) > di) sc[e] = -INFINITY;
+            }
+            float mx = fmaxf(sc[0], sc[1]);
+#pragma unroll
+            for (int e = 2; e < 16; e += 2) mx = fmaxf(mx, fmaxf(sc[e], sc[e + 1]));
+            return mx;
+        };
+        // the row maximum of the next unit is known: raise the running maximum if some row grew by more than 2^8
+        // (then rescale l and O: the C MFMAs of the previous unit must have written O first), set cum for its P
+        auto commit_max = [&](float mx, float cu_u) {
+            mx = half_swap_max(mx);
+            const float mxv = fmaf(mx, g.c, cu_u);       // log2 units, unit bias included
+#ifdef FWD_ABL_NOBRANCH
+            if (false) {
+#else
+            if (!__all(mxv - m <= RESCALE_LOG2)) {
+#endif
+                const float mn = fmaxf(m, mxv);
+                const float alpha = fast_exp2(m - mn);   // m = -inf at the first unit: alpha = 0, O and l are 0
+                m = mn;
+                l *= alpha;
+#ifndef FWD_ABL_NORESC
+                asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+                sfor<16 * DB>([&](auto rt) {
+                    constexpr int R = Cfg::R_O + decltype(rt)::value;
+                    agpr_put<R>(agpr_get<R>() * alpha);
+                });
+                asm volatile("s_nop 7" ::: "memory");    // VALU write of an AGPR -> MFMA read as C
+#endif
+            }
+            cum = cu_u - m;
+        };
         {
-            // not overlapped: A(0), then the row fragments of unit 1 and the K^T fragments of unit 0
+            // not overlapped: A(0), then the K rows of unit 1, the V^T fragments of unit 0, the maxima of unit 0
             const unsigned ub = lds0 + slot_c * SLOT;
-            sfor<2 * KS>([&](auto gt) { read_row(gt, ub); });
+            sfor<KS>([&](auto kt) { read_row(kt, ub); });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PIPE_FENCE();
-            sfor<NGX>([&](auto gt) { mfma_a_step(gt, scA, dpA); });
+            sfor<NGX>([&](auto gt) { mfma_a_step(gt, scA); });
             PIPE_FENCE();
-            sfor<2 * KS>([&](auto gt) { read_row(gt, ub + UB); });
+            sfor<KS>([&](auto kt) { read_row(kt, ub + UB); });
             sfor<NGY>([&](auto ft) { read_tr(ft, ub); });
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMA of A(0) must have landed
+            PIPE_FENCE();
+            const float mx0 = mask_max(scA, 0);
+            commit_max(mx0, cu);
             PIPE_FENCE();
         }
 
-        // One unit (tile t, half HB).  (sc, dp) hold S^T / dP^T of unit u (from the previous X), (scn, dpn) receive u + 1.
-        auto unit = [&](int t, auto hb_tag, f32x16& sc, f32x16& dp, f32x16& scn, f32x16& dpn) {
+        // One unit (tile t, half HB).  sc holds the masked S^T of unit u (from the previous X), scn receives u + 1.
+        auto unit = [&](int t, auto hb_tag, f32x16& sc, f32x16& scn) {
             constexpr int HB = decltype(hb_tag)::value;
             const int u = 2 * t + HB;
             const int slot_n = (slot_c + 1) & (NB - 1);
             const unsigned unext = lds0 + slot_n * SLOT + HB * UB;                        // unit u + 2
             const unsigned u1 = HB ? lds0 + slot_n * SLOT : lds0 + slot_c * SLOT + UB;    // unit u + 1
-            // rows of u+1 (read during X(u-1)) must have landed; the newest reads (K^T of unit u) may fly
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(lgkm_cap(2 * NGY)) : "memory");
+            const bool last = HB && t + 1 == ntiles;     // A(u+1) of the item's last unit is never used
+            // K rows of u+1 (read during X(u-1)) must have landed; the newest reads (V^T of unit u) may fly
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(fwd_lgkm_cap(2 * NGY)) : "memory");
             PIPE_FENCE();
-            if (HB && t + 1 == ntiles && n_n < nseq) load_q(n_bh, n_qb);     // Q / dO rows are dead: A(u+1) is never used
-            if (u >= umask) {                             // wave-uniform, at most 4 units per item
-                const int di = i - 32 * u - 4 * h5;       // key row part > di  <=>  key after query
-                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMA of A(u) must have landed
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if ((e & 3) + 8 * (e >> 2) > di) sc[e] = -INFINITY;
-            }
+            if (last && n_n < nseq) load_q(n_bh, n_qb);  // the Q rows are dead
             // ---------------- X(u)
             PIPE_FENCE();
-            unsigned dsf[8];                              // bf16 pairs: dS^T of unit u
-            float pe[16], de[16];
+            unsigned pf[8];                               // bf16 pairs: P^T of unit u
+            float pe[16];
             sfor<NGX>([&](auto gt) {
                 constexpr int fg = decltype(gt)::value;
-                mfma_a_step(gt, scn, dpn);
+                mfma_a_step(gt, scn);
                 PIPE_FENCE();
                 if constexpr (fg == 0 && HB == 0) {
                     // tile top, in the shadow of the first MFMA: the next tile must be complete before its rows are
@@ -311,81 +339,89 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pipe_kernel(DqArgs g) {
                     produce_begin();
                     PIPE_FENCE();
                 }
-                if constexpr (HB == 0 && (fg & 1) && (fg >> 1) < VM) {
-                    produce_piece(std::integral_constant<int, (fg >> 1)>{});
-                    if constexpr ((fg >> 1) == VM - 1) produce_end();
+                if constexpr ((fg & 1) && (fg >> 1) < PPU) {
+                    produce_piece(std::integral_constant<int, HB * PPU + (fg >> 1)>{});
+                    if constexpr (HB == 1 && (fg >> 1) == PPU - 1) produce_end();
                 }
                 read_row(gt, unext);
-                // P^T of this gap's elements, dS^T of the previous gap's: the multiply is inline asm, which the
-                // compiler's hazard recogniser does not look into, and a VALU that reads the result of the v_exp_f32
-                // right before it gets the OLD register contents on some lanes (transcendental forwarding hazard)
+                // P^T of this gap's elements; sum and pack of the previous gap's (a gap apart: the add is inline asm,
+                // which the hazard recogniser does not look into -- transcendental forwarding hazard)
                 if constexpr (fg >= 1 && fg <= 16 / Cfg::EPG) {
 #pragma unroll
                     for (int q = 0; q < Cfg::EPG; ++q) {
                         const int e = (fg - 1) * Cfg::EPG + q;
-                        de[e] = mul_np(pe[e], dp[e]);
-                        if (e & 1) dsf[e >> 1] = pack2(de[e - 1], de[e]);
+                        l = add_np(l, pe[e]);
+                        if (e & 1) pf[e >> 1] = pack2(pe[e - 1], pe[e]);
                     }
                 }
                 if constexpr (fg < 16 / Cfg::EPG) {
 #pragma unroll
                     for (int q = 0; q < Cfg::EPG; ++q) {
                         const int e = fg * Cfg::EPG + q;
-                        pe[e] = fast_exp2(fma_np(sc[e], g.c, cu));
+                        pe[e] = fast_exp2(fma_np(sc[e], g.c, cum));
                     }
                 }
                 PIPE_FENCE();
             });
-            // ---------------- Y(u): dQ MFMAs with the K^T fragments of unit u+1 between them
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(lgkm_cap(2 * KS)) : "memory");   // K^T fragments of unit u
+            // ---------------- Y(u): O MFMAs with the V^T fragments of unit u+1 between them
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(fwd_lgkm_cap(KS)) : "memory");   // V^T fragments of unit u
             PIPE_FENCE();
-            bf16x8 db[2] = {words_to_frag(dsf[0], dsf[1], dsf[2], dsf[3]),
-                                  words_to_frag(dsf[4], dsf[5], dsf[6], dsf[7])};
-            pin_frags(db[0], db[1]);                      // VALU write of dS -> MFMA read
+            bf16x8 pb[2] = {words_to_frag(pf[0], pf[1], pf[2], pf[3]), words_to_frag(pf[4], pf[5], pf[6], pf[7])};
+            pin_frags(pb[0], pb[1]);                      // VALU write of P -> MFMA read
             PIPE_FENCE();
+            float mxn = 0.f;
             sfor<NGY>([&](auto gt) {
                 constexpr int f = decltype(gt)::value;
                 constexpr int d = f % DB, s2 = f / DB;
-                mfma_acc<Cfg::R_DQ + 16 * d, Cfg::R_TK + 4 * f>(db[s2]);
+                mfma_acc<Cfg::R_O + 16 * d, Cfg::R_TV + 4 * f>(pb[s2]);
                 PIPE_FENCE();
                 read_tr(gt, u1);
+                // three MFMAs after the last one of A(u+1): its result has landed
+                if constexpr (f == 3) {
+                    if (!last) mxn = mask_max(scn, u + 1);
+                }
                 PIPE_FENCE();
             });
             cu += 32.f * csb;
+            if (!last) commit_max(mxn, cu);
+            PIPE_FENCE();
         };
 
         for (int t = 0; t < ntiles; ++t) {
-            unit(t, std::integral_constant<int, 0>{}, scA, dpA, scB, dpB);
-            unit(t, std::integral_constant<int, 1>{}, scB, dpB, scA, dpA);
+            unit(t, std::integral_constant<int, 0>{}, scA, scB);
+            unit(t, std::integral_constant<int, 1>{}, scB, scA);
             slot_c = (slot_c + 1) & (NB - 1);
         }
 
-        // ---- item done.  The last MFMAs must have written dQ before it is read back (nothing tells the compiler).
+        // ---- item done.  The last MFMAs must have written O before it is read back (nothing tells the compiler).
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-        // The next item's resident rows (requested a unit ago, younger than every tile request in flight) are waited
-        // for HERE, before the epilogue's stores are issued: after them a vmcnt(0) would also wait for the stores'
-        // acknowledgements.  The counted tile waits of the next item stay valid with stores outstanding: loads
-        // retire in order among themselves, stores only make the count conservative.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the next item's Q rows were requested at the top of the last unit, before that unit's PPU LDS-DMA pieces: loads
+        // retire in order, so at most PPU outstanding means they have landed.  Waited for before the epilogue's stores
+        // are issued (see attn_bwd_pipe.hip).
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPU) : "memory");
         PIPE_FENCE();
         {
-            // dQ^T has the query on the lane and dh down the registers: each wave turns its 32 queries x 64 columns
-            // at a time through 4 KiB of LDS (16-byte chunks XOR-swizzled with the row) and stores 128-byte row segments
+            const float lt = half_swap_sum(l);
+            const float inv = 1.f / lt;
+            if (h5 == 0 && i < S) g.lse[((long)b * H + h) * S + i] = (m + log2f(lt)) * LN2;
+            // O^T has the query on the lane and dh down the registers: each wave turns its 32 queries x 64 columns at a
+            // time through 4 KiB of LDS (16-byte chunks XOR-swizzled with the row) and stores 128-byte row segments
             const unsigned eb = lds0 + EPI + 4096 * w;
             const int erow = lane >> 3, ech = lane & 7;
-            bf16_t* const orow = g.dqkv + ((long)b * S + i0w) * rs + (long)h * DH;
+            bf16_t* const orow = g.out + (((long)b * S + i0w) * H + h) * DH;
+            const long ors = (long)H * DH;
             sfor<DH / 64>([&](auto pt) {
                 constexpr int half = decltype(pt)::value;
                 sfor<2>([&](auto dt) {
                     constexpr int dbk = 2 * half + decltype(dt)::value;
                     sfor<4>([&](auto gt) {
                         constexpr int gg = decltype(gt)::value;
-                        constexpr int r0 = Cfg::R_DQ + 16 * dbk + 4 * gg;
+                        constexpr int r0 = Cfg::R_O + 16 * dbk + 4 * gg;
                         bf16x4 v;
-                        v[0] = (bf16_t)(agpr_get<r0 + 0>() * g.scale);
-                        v[1] = (bf16_t)(agpr_get<r0 + 1>() * g.scale);
-                        v[2] = (bf16_t)(agpr_get<r0 + 2>() * g.scale);
-                        v[3] = (bf16_t)(agpr_get<r0 + 3>() * g.scale);
+                        v[0] = (bf16_t)(agpr_get<r0 + 0>() * inv);
+                        v[1] = (bf16_t)(agpr_get<r0 + 1>() * inv);
+                        v[2] = (bf16_t)(agpr_get<r0 + 2>() * inv);
+                        v[3] = (bf16_t)(agpr_get<r0 + 3>() * inv);
                         const int c16 = 4 * (dbk & 1) + gg;
                         lds_write_b64(eb + l31 * 128 + ((c16 ^ (l31 & 7)) * 16) + 8 * h5, v);
                     });
@@ -402,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pipe_kernel(DqArgs g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 8 * r + erow;
-                    if (i0w + row < S) *reinterpret_cast<bf16x8*>(orow + (long)row * rs + 64 * half + 8 * ech) = ov[r];
+                    if (i0w + row < S) *reinterpret_cast<bf16x8*>(orow + (long)row * ors + 64 * half + 8 * ech) = ov[r];
                 }
             });
         }
@@ -411,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pipe_kernel(DqArgs g) {
         c_n = n_n;
         c_bh = n_bh;
         c_qb = n_qb;
-        sfor<16 * DB>([&](auto rt) { agpr_zero<Cfg::R_DQ + decltype(rt)::value>(); });
+        sfor<16 * DB>([&](auto rt) { agpr_zero<Cfg::R_O + decltype(rt)::value>(); });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PIPE_FENCE();
     }
@@ -420,13 +456,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pipe_kernel(DqArgs g) {
 
 }  // namespace
 
-// dQ with the statistics of attn_bwd_pipe.hip's pre-pass (nd32 = -delta, rows padded to Sp)
-int mgx_attn_bwd_dq_pipe(const void* dout, const void* qkv, const float* lse, const float* nd32, const float* slopes,
-                         void* dqkv, int B, int S, int H, int dh, hipStream_t st) {
+int mgx_attn_fwd_pipe(const void* qkv, const float* slopes, void* out, float* lse, int B, int S, int H, int dh,
+                      hipStream_t st) {
     const int Sp = (S + 63) / 64 * 64;
-    const float scale = 1.0f / sqrtf((float)dh);
-    const float c = LOG2E * scale;
-    DqArgs a{(const bf16_t*)dout, (const bf16_t*)qkv, lse, nd32, slopes, (bf16_t*)dqkv, B, S, Sp, H, c, scale, 0, 0, 0};
+    const float c = LOG2E / sqrtf((float)dh);
+    FwdArgs a{(const bf16_t*)qkv, slopes, (bf16_t*)out, lse, B, S, Sp, H, c, 0, 0, 0};
     a.nqb = (S + 127) / 128;
     a.np = (a.nqb + 1) / 2;
     a.nwork = B * H * a.np;
@@ -439,9 +473,9 @@ int mgx_attn_bwd_dq_pipe(const void* dout, const void* qkv, const float* lse, co
     }
     const int grid = a.nwork < n_cu ? a.nwork : n_cu;     // one persistent workgroup per CU
     if (dh == 64)
-        hipLaunchKernelGGL((attn_bwd_dq_pipe_kernel<64>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_fwd_pipe_kernel<64>), dim3(grid), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((attn_bwd_dq_pipe_kernel<128>), dim3(grid), dim3(256), 0, st, a);
-    MGX_CHECK_LAUNCH("attn_bwd_dq_pipe");
+        hipLaunchKernelGGL((attn_fwd_pipe_kernel<128>), dim3(grid), dim3(256), 0, st, a);
+    MGX_CHECK_LAUNCH("attn_fwd_pipe");
     return MGX_OK;
 }
