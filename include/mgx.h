@@ -254,10 +254,12 @@ int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2, const flo
  *   as the two-launch path stores it); pre [M,N] bf16 is the saved pre-activation (ld = ldc).
  *   colpart [mgx_gemm_nt_dact_colpart_floats(M,N)] fp32 (may be NULL) = [2*ceil(M/256), N] partial column sums of
  *   the rounded C, one row per 128-row slab (plus one for the second wave row of each tile): their sum over rows is
- *   the bias gradient of linear1; every entry is written (no zero-fill needed), fixed order. */
+ *   the bias gradient of linear1; every entry is written (no zero-fill needed), fixed order.
+ *   dbias [N] fp32 (may be NULL; needs colpart): that sum, formed by a second small launch in a fixed order. */
 long mgx_gemm_nt_dact_colpart_floats(int M, int N);
-int mgx_gemm_nt_dact_bf16(const void* A, const void* Bt, const void* pre, void* C, float* colpart, int M, int N, int K,
-                          int lda, int ldb, int ldc, int act, float p_drop, unsigned long long seed, void* stream);
+int mgx_gemm_nt_dact_bf16(const void* A, const void* Bt, const void* pre, void* C, float* colpart, float* dbias, int M,
+                          int N, int K, int lda, int ldb, int ldc, int act, float p_drop, unsigned long long seed,
+                          void* stream);
 /* TN (weight gradients): C[M,N] = A[K,M]^T . B[K,N], bf16 inputs, split over K into fp32 slabs in
  * `workspace` (mgx_gemm_tn_workspace_floats() floats) and reduced in a fixed order (deterministic);
  * C is fp32 or bf16 (out_dtype).  M, N, lda, ldb multiples of 8. */

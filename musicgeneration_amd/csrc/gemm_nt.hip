@@ -422,6 +422,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
     }
 }
 
+// out[c] = sum_r part[r][c]: 64 columns x 16 row slices per workgroup, fixed summation order
+__global__ __launch_bounds__(1024) void nt_colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                  int rows, int n) {
+    __shared__ float sh[16][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < n) {
+        int r = slice;
+        for (; r + 16 < rows; r += 32) {
+            s0 += part[(size_t)r * n + c];
+            s1 += part[(size_t)(r + 16) * n + c];
+        }
+        if (r < rows) s0 += part[(size_t)r * n + c];
+    }
+    sh[slice][lane] = s0 + s1;
+    __syncthreads();
+    if (slice == 0 && c < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += sh[k][lane];
+        out[c] = s;
+    }
+}
+
 }  // namespace
 
 static int nt_check(const char* fn, const void* A, const void* Bt, const void* C, int M, int N, int K, int lda, int ldb,
@@ -464,11 +489,12 @@ extern "C" int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2
 
 extern "C" long mgx_gemm_nt_dact_colpart_floats(int M, int N) { return (long)((M + BM - 1) / BM) * 2 * N; }
 
-extern "C" int mgx_gemm_nt_dact_bf16(const void* A, const void* Bt, const void* pre, void* C, float* colpart, int M, int N,
-                                     int K, int lda, int ldb, int ldc, int act, float p_drop, unsigned long long seed,
-                                     void* stream) {
+extern "C" int mgx_gemm_nt_dact_bf16(const void* A, const void* Bt, const void* pre, void* C, float* colpart, float* dbias,
+                                     int M, int N, int K, int lda, int ldb, int ldc, int act, float p_drop,
+                                     unsigned long long seed, void* stream) {
     if (int rc = nt_check("mgx_gemm_nt_dact_bf16", A, Bt, C, M, N, K, lda, ldb, ldc)) return rc;
     MGX_REQUIRE(pre, MGX_EINVAL, "mgx_gemm_nt_dact_bf16: null pre-activation");
+    MGX_REQUIRE(!dbias || colpart, MGX_EINVAL, "mgx_gemm_nt_dact_bf16: dbias needs the colpart workspace");
     MGX_REQUIRE(act == MGX_ACT_GELU || act == MGX_ACT_RELU, MGX_EINVAL, "mgx_gemm_nt_dact_bf16: bad act %d", act);
     MGX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, MGX_EINVAL, "mgx_gemm_nt_dact_bf16: p_drop=%f", p_drop);
     NtArgs g{(const char*)A, (const char*)Bt, (bf16_t*)C, nullptr, nullptr, nullptr, (const bf16_t*)pre, colpart,
@@ -478,5 +504,11 @@ extern "C" int mgx_gemm_nt_dact_bf16(const void* A, const void* Bt, const void* 
     if (act == MGX_ACT_GELU) { if (drop) NT_LAUNCH(EPI_DACT, MGX_ACT_GELU, true); else NT_LAUNCH(EPI_DACT, MGX_ACT_GELU, false); }
     else { if (drop) NT_LAUNCH(EPI_DACT, MGX_ACT_RELU, true); else NT_LAUNCH(EPI_DACT, MGX_ACT_RELU, false); }
     MGX_CHECK_LAUNCH("gemm_nt_dact");
+    if (dbias) {
+        const int rows = 2 * ((M + BM - 1) / BM);
+        hipLaunchKernelGGL(nt_colpart_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, (hipStream_t)stream, colpart,
+                           dbias, rows, N);
+        MGX_CHECK_LAUNCH("gemm_nt_dact_reduce");
+    }
     return MGX_OK;
 }

@@ -285,10 +285,11 @@ def gemm_nt_dact(dy, bt, pre, act, p_drop=0.0, seed=0):
         raise ValueError(f"gemm_nt_dact: dy {tuple(dy.shape)} bt {tuple(bt.shape)} pre {tuple(pre.shape)}")
     c = torch.empty(M, N, dtype=torch.bfloat16, device=dy.device)
     part = torch.empty(int(lib.mgx_gemm_nt_dact_colpart_floats(M, N)), dtype=torch.float32, device=dy.device)
+    dbias = torch.empty(N, dtype=torch.float32, device=dy.device)
     with _timed("gemm_nt", 2.0 * M * N * K):
-        check(lib.mgx_gemm_nt_dact_bf16(_p(dy), _p(bt), _p(pre), _p(c), _p(part), M, N, K, K, K, N, _ACT[act],
+        check(lib.mgx_gemm_nt_dact_bf16(_p(dy), _p(bt), _p(pre), _p(c), _p(part), _p(dbias), M, N, K, K, K, N, _ACT[act],
                                         float(p_drop), seed, _stream()), "mgx_gemm_nt_dact_bf16")
-    return c, part.view(-1, N).sum(0)
+    return c, dbias
 
 
 def gemm_tn(a, b, out_dtype=torch.float32, tag="gemm_tn"):
