@@ -73,30 +73,33 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_mfma_kernel(const bf16_t*
 
     const int kmax = min(q0 + QB, S);                    // keys [0, kmax)
     const int ntiles = (kmax + 63) / 64;
-    // Double-buffered staging, one barrier per tile: while tile t is consumed from buffer t&1,
-    // tile t+1 (already in registers) is written to the other buffer and tile t+2 is fetched.
+    // Keys are walked from the diagonal tile BACKWARDS: with ALiBi the largest scores sit next to the diagonal, so the
+    // running maximum is right after the first tile and the rescale below stays the exception (walking forwards, the
+    // heads with large slopes raise it by more than 2^8 on every tile).
+    // Double-buffered staging, one barrier per tile: while step n is consumed from buffer n&1, the tile of step n+1
+    // (already in registers) is written to the other buffer and the tile of step n+2 is fetched.
     TileRegs<DH, NT> kr, vr;
-    tile_load<DH, NT>(kr, kp, rs, 0, S, tid);
-    tile_load<DH, NT>(vr, vp, rs, 0, S, tid);
+    tile_load<DH, NT>(kr, kp, rs, (ntiles - 1) * 64, S, tid);
+    tile_load<DH, NT>(vr, vp, rs, (ntiles - 1) * 64, S, tid);
     tile_store<DH, NT>(kr, smem, tid);
     tile_store<DH, NT>(vr, smem + TB, tid);
     if (ntiles > 1) {
-        tile_load<DH, NT>(kr, kp, rs, 64, S, tid);
-        tile_load<DH, NT>(vr, vp, rs, 64, S, tid);
+        tile_load<DH, NT>(kr, kp, rs, (ntiles - 2) * 64, S, tid);
+        tile_load<DH, NT>(vr, vp, rs, (ntiles - 2) * 64, S, tid);
     }
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const int j0 = t * 64;
-        const char* Ks = smem + (t & 1) * 2 * TB;
+    for (int n = 0; n < ntiles; ++n) {
+        const int j0 = (ntiles - 1 - n) * 64;
+        const char* Ks = smem + (n & 1) * 2 * TB;
         const char* Vs = Ks + TB;
-        if (t + 1 < ntiles) {
-            char* Kn = smem + ((t + 1) & 1) * 2 * TB;
+        if (n + 1 < ntiles) {
+            char* Kn = smem + ((n + 1) & 1) * 2 * TB;
             tile_store<DH, NT>(kr, Kn, tid);
             tile_store<DH, NT>(vr, Kn + TB, tid);
         }
-        if (t + 2 < ntiles) {
-            tile_load<DH, NT>(kr, kp, rs, j0 + 128, S, tid);
-            tile_load<DH, NT>(vr, vp, rs, j0 + 128, S, tid);
+        if (n + 2 < ntiles) {
+            tile_load<DH, NT>(kr, kp, rs, j0 - 128, S, tid);
+            tile_load<DH, NT>(vr, vp, rs, j0 - 128, S, tid);
         }
         if (j0 <= qw0 + 31) {                             // wave-uniform
             f32x16 s[2];

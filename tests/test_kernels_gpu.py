@@ -107,17 +107,19 @@ def test_alibi_attention_bf16_asymmetric_exact():
 
 @pytest.mark.parametrize("dh", [64, 128])
 def test_alibi_attention_bf16_rescale_branch(dh):
-    """Forces the deferred-rescale branch of the flash kernel (guide rule 26): one key per row block
-    is spiked so the running max jumps by far more than the threshold at a chosen tile, after
-    tiles that were accumulated against the old max; compared on the FULL tensor."""
+    """Forces the deferred-rescale branch of the flash kernel (guide rule 26): keys are spiked so the running max
+    jumps by far more than the threshold (2^8) at a chosen tile, after tiles that were accumulated against the old
+    max -- both for a kernel that walks the keys forwards (spike right before the query) and for one that walks them
+    backwards from the diagonal (spike 230 keys before the query); compared on the FULL tensor."""
     ops = _ops()
     B, S, H = 1, 448, 2
     g = torch.Generator().manual_seed(11)
     q = 0.3 * torch.randn(B, S, H, dh, generator=g)
     k = 0.3 * torch.randn(B, S, H, dh, generator=g)
     v = torch.randn(B, S, H, dh, generator=g)
-    for j in (70, 200, 330):                      # keys in tiles 1, 3, 5
-        k[0, j] = 6.0 * q[0, j + 40] / q[0, j + 40].norm(dim=-1, keepdim=True)   # aligned with a later query
+    for j, ahead in ((70, 40), (200, 40), (330, 40), (10, 230), (100, 230)):
+        k[0, j] = 30.0 * q[0, j + ahead] / q[0, j + ahead].norm(dim=-1, keepdim=True)   # aligned with a later query:
+        # score 30 * |q| / sqrt(dh) = 9, i.e. 13 in log2 units
     qkv = torch.cat([q.reshape(B, S, -1), k.reshape(B, S, -1), v.reshape(B, S, -1)], -1).bfloat16()
     dout = torch.randn(B, S, H * dh, generator=g).bfloat16()
     slopes = torch.tensor(O.alibi_slopes(H), dtype=torch.float32)
