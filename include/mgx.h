@@ -241,25 +241,24 @@ int mgx_cast_shadow_bf16(int count, const float* const* src, void* const* dst, v
  * Replace Conv1d.forward (base_layers.py:54-57) and nn.Linear (alibi_unified.py:90,92) and their
  * autograd GEMMs.  Tile 256x256x64, fp32 accumulate.
  * NT: C[M,N] = A[M,K] . Bt[N,K]^T (+ bias[N] fp32) (+ res[M,N] bf16); all bf16, K % 64 == 0, N % 8 == 0,
- *     lda/ldb/ldc multiples of 8.  act = -1: nothing more.  act = MGX_ACT_*: C receives the
- *     pre-activation and C2[M,N] = dropout(act(C)) (dropout keyed by (seed, m*N+n), the same mask
- *     mgx_bias_act_bwd regenerates); res must be NULL then.
+ *     lda/ldb/ldc multiples of 8.  act = -1: nothing more.  act = MGX_ACT_*: with pre = the bf16-rounded
+ *     A.Bt^T + bias, C2[M,N] = dropout(act(pre)) (alibi_unified.py:90-91; dropout keyed by (seed, m*N+n), the same
+ *     mask mgx_bias_act_bwd regenerates) and C[M,N] = act'(pre) * mask/(1-p), the derivative factor the backward
+ *     multiplies by (mgx_gemm_nt_dfac_bf16); the pre-activation itself is not stored.  res must be NULL then.
  */
 int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2, const float* bias, const void* res,
                      int M, int N, int K, int lda, int ldb, int ldc, int act, float p_drop,
                      unsigned long long seed, void* stream);
 /* NT with the backward of `drop(activation(.))` (alibi_unified.py:90-91) as its epilogue: the dgrad GEMM of
- * linear2 (autograd of alibi_unified.py:92) followed by what mgx_bias_act_bwd does, in one launch:
- *   C[M,N] = (A[M,K] . Bt[N,K]^T) * mask/(1-p) * act'(pre[M,N])      (the GEMM result is rounded to bf16 first,
- *   as the two-launch path stores it); pre [M,N] bf16 is the saved pre-activation (ld = ldc).
- *   colpart [mgx_gemm_nt_dact_colpart_floats(M,N)] fp32 (may be NULL) = [2*ceil(M/256), N] partial column sums of
+ * linear2 (autograd of alibi_unified.py:92) times the derivative factor the forward left, in one launch:
+ *   C[M,N] = (A[M,K] . Bt[N,K]^T) * fac[M,N]      fac [M,N] bf16 (ld = ldc) = C of mgx_gemm_nt_bf16 with act >= 0;
+ *   colpart [mgx_gemm_nt_dfac_colpart_floats(M,N)] fp32 (may be NULL) = [2*ceil(M/256), N] partial column sums of
  *   the rounded C, one row per 128-row slab (plus one for the second wave row of each tile): their sum over rows is
  *   the bias gradient of linear1; every entry is written (no zero-fill needed), fixed order.
  *   dbias [N] fp32 (may be NULL; needs colpart): that sum, formed by a second small launch in a fixed order. */
-long mgx_gemm_nt_dact_colpart_floats(int M, int N);
-int mgx_gemm_nt_dact_bf16(const void* A, const void* Bt, const void* pre, void* C, float* colpart, float* dbias, int M,
-                          int N, int K, int lda, int ldb, int ldc, int act, float p_drop, unsigned long long seed,
-                          void* stream);
+long mgx_gemm_nt_dfac_colpart_floats(int M, int N);
+int mgx_gemm_nt_dfac_bf16(const void* A, const void* Bt, const void* fac, void* C, float* colpart, float* dbias, int M,
+                          int N, int K, int lda, int ldb, int ldc, void* stream);
 /* TN (weight gradients): C[M,N] = A[K,M]^T . B[K,N], bf16 inputs, split over K into fp32 slabs in
  * `workspace` (mgx_gemm_tn_workspace_floats() floats) and reduced in a fixed order (deterministic);
  * C is fp32 or bf16 (out_dtype).  M, N, lda, ldb multiples of 8. */

@@ -1,5 +1,8 @@
 // bf16 MFMA GEMM, NT form, for the projections of the decoder block (gfx950):
 //   C[M,N] = A[M,K] . Bt[N,K]^T  (+ bias[N]) (+ residual[M,N]) (-> activation / activation backward)
+// The activation epilogue writes dropout(act(pre)) and, for the backward, the derivative factor
+// fac = act'(pre) * mask / (1 - p) in bf16; the activation-backward dgrad is then (A . Bt^T) * fac: one multiply per
+// element instead of erf + exp + the dropout hash (the epilogue is serial with the main loop on a CU).
 // Replaces Conv1d.forward (base_layers.py:54-57: reshape -> matmul -> +b), the nn.Linear calls of
 // DecoderBlock.forward (alibi_unified.py:90,92) and the dgrad GEMMs autograd derives from them.
 //
@@ -34,15 +37,19 @@ struct NtArgs {
     bf16_t* C2;              // second output (EPI_ACT) or null
     const float* bias;       // [N] or null
     const bf16_t* res;       // [M,N] or null (EPI_PLAIN)
-    const bf16_t* pre;       // [M,N] pre-activation (EPI_DACT)
-    float* colpart;          // [gridM, N] per-row-tile column sums of C (EPI_DACT) or null
+    const bf16_t* fac;       // [M,N] derivative factor written by the EPI_ACT forward (EPI_DFAC)
+    float* colpart;          // [gridM, N] per-row-tile column sums of C (EPI_DFAC) or null
     int M, N, K;
     int lda, ldb, ldc;
     float p_drop;
     unsigned long long seed;
 };
 
-enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DACT = 2 };
+// first column (inside the block tile) of wave column wc's 32-column slice in Bt half tile X.  Measured and not kept:
+// 64 (wc) + 32 (X), which makes a wave's two slices one 128-byte line of C (bias epilogue 208 -> 214 us, activation
+// epilogue 320 -> 350 us at M=32768 N=4096 K=1024, same box)
+#define NT_COL0(wc, X) (128 * (X) + 32 * (wc))
+enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_DFAC = 2 };
 
 // bijective XCD remap: blocks that share an XCD (id % 8) get a contiguous run of tile indices
 __device__ __forceinline__ int xcd_remap(int id, int n) {
@@ -50,20 +57,9 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float z = x * 0.70710678118654752440f;
-    const float az = fabsf(z);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);
-    const float erfv = copysignf(fmaf(-poly * t, e, 1.f), z);
-    return 0.5f * x * (1.f + erfv);
-}
-// d/dx gelu(x) = Phi(x) + x * phi(x)
-__device__ __forceinline__ float gelu_grad_fast(float x) {
+// gelu(x) = x * Phi(x) and d/dx gelu(x) = Phi(x) + x * phi(x) from one evaluation of erf (Abramowitz-Stegun 7.1.26,
+// |error| < 1.5e-7) and of exp(-x^2 / 2)
+__device__ __forceinline__ void gelu_val_grad(float x, float& y, float& dy) {
     const float z = x * 0.70710678118654752440f;
     const float az = fabsf(z);
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.f));
@@ -73,7 +69,9 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
     poly = fmaf(poly, t, 0.254829592f);
     const float e = __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);      // exp(-x^2/2)
     const float erfv = copysignf(fmaf(-poly * t, e, 1.f), z);
-    return fmaf(x * 0.3989422804014327f, e, 0.5f * (1.f + erfv));
+    const float cdf = fmaf(0.5f, erfv, 0.5f);
+    y = x * cdf;
+    dy = fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
@@ -125,7 +123,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
             const int row = 16 * w + 8 * i + (lane >> 3);
             const int ch = (lane & 7) ^ ((row >> 1) & 7);
             sa[X][i] = (unsigned)(((long)min(m0 + 128 * X + row, g.M - 1) * g.lda + ch * 8) * 2);
-            sb[X][i] = (unsigned)(((long)min(n0 + 128 * X + row, g.N - 1) * g.ldb + ch * 8) * 2);
+            sb[X][i] = (unsigned)(((long)min(n0 + NT_COL0(row >> 5, X) + (row & 31), g.N - 1) * g.ldb + ch * 8) * 2);
         }
     const int nk = g.K / BK;
     char* const stage_base = smem + 2048 * w;
@@ -247,167 +245,155 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
     const unsigned thr16 = mgx_drop_thr16(g.p_drop);
     const float keep_scale = mgx_keep_scale(thr16);
     const int nsw = (g4 & 1) ? 16 + 4 * (g4 - 1) : 4 * g4;
+    // the second operand of the epilogue (residual / derivative factor) for BOTH of the wave's 256 x 32 slices,
+    // requested up front with clamped addresses (no branch: the 16 loads leave back to back into the registers the
+    // fragments have left, and one round trip is exposed per tile), 16 bytes per lane in the layout of the stores
+    // below and turned back into the accumulator layout by the same 16-lane-row swap
+    const bool has_side = EPI == EPI_DFAC || (EPI == EPI_PLAIN && g.res);
+    uint4 raw[2][2][4];
+    if (has_side) {
+        const bf16_t* sp = EPI == EPI_DFAC ? g.fac : g.res;
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const int nb = n0 + 128 * qb + 32 * wc;
-        f32x4 bv[2];
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int nc = min(n0 + NT_COL0(wc, qb) + nsw, g.N - 8);
+                    const int mc = min(m0 + 128 * qa + 64 * wr + 16 * i + l15, g.M - 1);
+                    raw[qb][qa][i] = *reinterpret_cast<const uint4*>(sp + (long)mc * g.ldc + nc);
+                }
+    }
+    f32x4 bv[2][2];
+    float csum[2][2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int n = nb + 16 * j + 4 * g4;
-            if (g.bias && n < g.N) bv[j] = *reinterpret_cast<const f32x4*>(g.bias + n);
+            bv[qb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int n = n0 + NT_COL0(wc, qb) + 16 * j + 4 * g4;
+            if (EPI != EPI_DFAC && g.bias && n < g.N) bv[qb][j] = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) csum[qb][j][r] = 0.f;
         }
-        // the second operand of the epilogue (residual / pre-activation) for the wave's whole 256 x 32 slice, requested
-        // up front with clamped addresses (no branch: the 8 loads leave back to back and one round trip is exposed per
-        // slice instead of one per 16-row block), 16 bytes per lane in the layout of the stores below and turned back
-        // into the accumulator layout by the same 16-lane-row swap
-        uint2 side[2][4][2];
-        const bool has_side = EPI == EPI_DACT || (EPI == EPI_PLAIN && g.res);
+    auto block = [&](int qa, int qb, int i) {
+        const int nb = n0 + NT_COL0(wc, qb);
+        const int m = m0 + 128 * qa + 64 * wr + 16 * i + l15;
+        const bool row_ok = m < g.M;
+        const int mc = row_ok ? m : g.M - 1;
+        float v[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[j][r] = acc[qa][qb][i][j][r] + bv[qb][j][r];
         if (has_side) {
-            const bf16_t* sp = EPI == EPI_DACT ? g.pre : g.res;
-            const int nc = min(nb + nsw, g.N - 8);
-            uint4 raw[2][4];
+            // residual: C = v + res; derivative factor: C = v * fac (columns past N: some real value, never stored)
+            const uint4 rw = raw[qb][qa][i];
+            auto s0 = __builtin_amdgcn_permlane16_swap(rw.x, rw.z, false, false);
+            auto s1 = __builtin_amdgcn_permlane16_swap(rw.y, rw.w, false, false);
 #pragma unroll
-            for (int qa = 0; qa < 2; ++qa)
+            for (int j = 0; j < 2; ++j) {
+                const float x[4] = {bf_lo(s0[j]), bf_hi(s0[j]), bf_lo(s1[j]), bf_hi(s1[j])};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int mc = min(m0 + 128 * qa + 64 * wr + 16 * i + l15, g.M - 1);
-                    raw[qa][i] = *reinterpret_cast<const uint4*>(sp + (long)mc * g.ldc + nc);
-                }
-#pragma unroll
-            for (int qa = 0; qa < 2; ++qa)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    auto s0 = __builtin_amdgcn_permlane16_swap(raw[qa][i].x, raw[qa][i].z, false, false);
-                    auto s1 = __builtin_amdgcn_permlane16_swap(raw[qa][i].y, raw[qa][i].w, false, false);
-                    side[qa][i][0] = make_uint2(s0[0], s1[0]);
-                    side[qa][i][1] = make_uint2(s0[1], s1[1]);
-                }
+                for (int r = 0; r < 4; ++r) v[j][r] = EPI == EPI_DFAC ? v[j][r] * x[r] : v[j][r] + x[r];
+            }
         }
-        float csum[2][4];
-        if (EPI == EPI_DACT) {
+        unsigned o[2][2], o2[2][2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) csum[j][r] = 0.f;
+        for (int j = 0; j < 2; ++j) {
+            o[j][0] = pack2(v[j][0], v[j][1]);
+            o[j][1] = pack2(v[j][2], v[j][3]);
         }
+        if (EPI == EPI_DFAC) {
+            // column sums of the ROUNDED values (what a separate pass over C would add up)
+            if (row_ok) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    csum[qb][j][0] += bf_lo(o[j][0]);
+                    csum[qb][j][1] += bf_hi(o[j][0]);
+                    csum[qb][j][2] += bf_lo(o[j][1]);
+                    csum[qb][j][3] += bf_hi(o[j][1]);
+                }
+            }
+        }
+        if (EPI == EPI_ACT) {
+            // o2 = dropout(act(pre)), o = act'(pre) * mask / (1 - p); both see the pre-activation rounded to bf16
+            // (the value an unfused pass would read back)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = nb + 16 * j + 4 * g4;
+                float y[4], f[4];
+                const float x[4] = {bf_lo(o[j][0]), bf_hi(o[j][0]), bf_lo(o[j][1]), bf_hi(o[j][1])};
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    float y0, y1, f0, f1;
+                    if (ACT == MGX_ACT_RELU) {
+                        y0 = fmaxf(x[r], 0.f);
+                        y1 = fmaxf(x[r + 1], 0.f);
+                        f0 = x[r] > 0.f ? 1.f : 0.f;
+                        f1 = x[r + 1] > 0.f ? 1.f : 0.f;
+                    } else {
+                        gelu_val_grad(x[r], y0, f0);
+                        gelu_val_grad(x[r + 1], y1, f1);
+                    }
+                    if (DROP) {
+                        bool k0, k1;
+                        mgx_keep_pair(g.seed, (unsigned long long)((long)mc * g.N + n + r), thr16, k0, k1);
+                        const float s0 = k0 ? keep_scale : 0.f, s1 = k1 ? keep_scale : 0.f;
+                        y0 *= s0;
+                        f0 *= s0;
+                        y1 *= s1;
+                        f1 *= s1;
+                    }
+                    y[r] = y0;
+                    y[r + 1] = y1;
+                    f[r] = f0;
+                    f[r + 1] = f1;
+                }
+                o2[j][0] = pack2(y[0], y[1]);
+                o2[j][1] = pack2(y[2], y[3]);
+                o[j][0] = pack2(f[0], f[1]);
+                o[j][1] = pack2(f[2], f[3]);
+            }
+        }
+        // 16-lane-row swap: odd rows of the j = 0 word <-> even rows of the j = 1 word
+        const int n = nb + nsw;
+        {
+            auto s0 = __builtin_amdgcn_permlane16_swap(o[0][0], o[1][0], false, false);
+            auto s1 = __builtin_amdgcn_permlane16_swap(o[0][1], o[1][1], false, false);
+            if (row_ok && n < g.N)
+                *reinterpret_cast<uint4*>(g.C + (long)m * g.ldc + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+        if (EPI == EPI_ACT) {
+            auto s0 = __builtin_amdgcn_permlane16_swap(o2[0][0], o2[1][0], false, false);
+            auto s1 = __builtin_amdgcn_permlane16_swap(o2[0][1], o2[1][1], false, false);
+            if (row_ok && n < g.N)
+                *reinterpret_cast<uint4*>(g.C2 + (long)m * g.ldc + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+    };
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int qa = 0; qa < 2; ++qa)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + 128 * qa + 64 * wr + 16 * i + l15;
-                const bool row_ok = m < g.M;
-                const int mc = row_ok ? m : g.M - 1;
-                float v[2][4];
+            for (int i = 0; i < 4; ++i) block(qa, qb, i);
+    if (EPI == EPI_DFAC && g.colpart) {
+        // wave's partial column sums over its 128 rows of this tile: reduce the 16 lanes of a row group
+        // (xor 1, 2, 4, 8), then lane l15 == 0 of each g4 adds 4 values per j.  Two wave rows (wr) share a
+        // column: fixed slots [bm][wr][N], summed by nt_colpart_reduce_kernel in a fixed order.
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[j][r] = acc[qa][qb][i][j][r] + bv[j][r];
-                unsigned o[2][2], o2[2][2];
-                if (EPI == EPI_PLAIN && g.res) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const uint2 rr = side[qa][i][j];         // columns past N: some real value, never stored
-                        v[j][0] += bf_lo(rr.x);
-                        v[j][1] += bf_hi(rr.x);
-                        v[j][2] += bf_lo(rr.y);
-                        v[j][3] += bf_hi(rr.y);
-                    }
-                }
-                if (EPI == EPI_DACT) {
-                    // v = d(activation output); C = v * mask/(1-p) * act'(pre)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int n = nb + 16 * j + 4 * g4;
-                        const uint2 pp = side[qa][i][j];
-                        const float x[4] = {bf_lo(pp.x), bf_hi(pp.x), bf_lo(pp.y), bf_hi(pp.y)};
-#pragma unroll
-                        for (int r = 0; r < 4; r += 2) {
-                            // the unfused path rounds dh to bf16 before bias_act_bwd reads it
-                            float d0 = (float)(bf16_t)v[j][r], d1 = (float)(bf16_t)v[j][r + 1];
-                            if (DROP) {
-                                bool k0, k1;
-                                mgx_keep_pair(g.seed, (unsigned long long)((long)mc * g.N + n + r), thr16, k0, k1);
-                                d0 = k0 ? d0 * keep_scale : 0.f;
-                                d1 = k1 ? d1 * keep_scale : 0.f;
-                            }
-                            const float g0 = ACT == MGX_ACT_RELU ? (x[r] > 0.f ? 1.f : 0.f) : gelu_grad_fast(x[r]);
-                            const float g1 = ACT == MGX_ACT_RELU ? (x[r + 1] > 0.f ? 1.f : 0.f) : gelu_grad_fast(x[r + 1]);
-                            v[j][r] = d0 * g0;
-                            v[j][r + 1] = d1 * g1;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    o[j][0] = pack2(v[j][0], v[j][1]);
-                    o[j][1] = pack2(v[j][2], v[j][3]);
-                }
-                if (EPI == EPI_DACT) {
-                    // column sums of the ROUNDED values (what a separate pass over C would add up)
-                    if (row_ok) {
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            csum[j][0] += bf_lo(o[j][0]);
-                            csum[j][1] += bf_hi(o[j][0]);
-                            csum[j][2] += bf_lo(o[j][1]);
-                            csum[j][3] += bf_hi(o[j][1]);
-                        }
-                    }
-                }
-                if (EPI == EPI_ACT) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int n = nb + 16 * j + 4 * g4;
-                        float y[4];
-                        // the activation sees the stored (rounded) pre-activation, as the unfused kernel does
-                        const float x[4] = {bf_lo(o[j][0]), bf_hi(o[j][0]), bf_lo(o[j][1]), bf_hi(o[j][1])};
-#pragma unroll
-                        for (int r = 0; r < 4; r += 2) {
-                            float y0 = ACT == MGX_ACT_RELU ? fmaxf(x[r], 0.f) : gelu_fast(x[r]);
-                            float y1 = ACT == MGX_ACT_RELU ? fmaxf(x[r + 1], 0.f) : gelu_fast(x[r + 1]);
-                            if (DROP) {
-                                bool k0, k1;
-                                mgx_keep_pair(g.seed, (unsigned long long)((long)mc * g.N + n + r), thr16, k0, k1);
-                                y0 = k0 ? y0 * keep_scale : 0.f;
-                                y1 = k1 ? y1 * keep_scale : 0.f;
-                            }
-                            y[r] = y0;
-                            y[r + 1] = y1;
-                        }
-                        o2[j][0] = pack2(y[0], y[1]);
-                        o2[j][1] = pack2(y[2], y[3]);
-                    }
-                }
-                // 16-lane-row swap: odd rows of the j = 0 word <-> even rows of the j = 1 word
-                const int n = nb + nsw;
-                {
-                    auto s0 = __builtin_amdgcn_permlane16_swap(o[0][0], o[1][0], false, false);
-                    auto s1 = __builtin_amdgcn_permlane16_swap(o[0][1], o[1][1], false, false);
-                    if (row_ok && n < g.N)
-                        *reinterpret_cast<uint4*>(g.C + (long)m * g.ldc + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                }
-                if (EPI == EPI_ACT) {
-                    auto s0 = __builtin_amdgcn_permlane16_swap(o2[0][0], o2[1][0], false, false);
-                    auto s1 = __builtin_amdgcn_permlane16_swap(o2[0][1], o2[1][1], false, false);
-                    if (row_ok && n < g.N)
-                        *reinterpret_cast<uint4*>(g.C2 + (long)m * g.ldc + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                }
-            }
-        if (EPI == EPI_DACT && g.colpart) {
-            // wave's partial column sums over its 128 rows of this tile: reduce the 16 lanes of a row group
-            // (xor 1, 2, 4, 8), then lane l15 == 0 of each g4 adds 4 values per j.  Two wave rows (wr) share a
-            // column: fixed slots [bm][wr][N], summed by the host-side reduction in a fixed order.
+        for (int qb = 0; qb < 2; ++qb) {
+            const int nb = n0 + NT_COL0(wc, qb);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float s = csum[j][r];
+                    float s = csum[qb][j][r];
                     s += __shfl_xor(s, 1, 64);
                     s += __shfl_xor(s, 2, 64);
                     s += __shfl_xor(s, 4, 64);
                     s += __shfl_xor(s, 8, 64);
-                    csum[j][r] = s;
+                    csum[qb][j][r] = s;
                 }
             if (l15 == 0) {
 #pragma unroll
@@ -415,7 +401,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
                     const int n = nb + 16 * j + 4 * g4;
                     if (n < g.N)
                         *reinterpret_cast<f32x4*>(g.colpart + ((long)bm * 2 + wr) * g.N + n) =
-                            f32x4{csum[j][0], csum[j][1], csum[j][2], csum[j][3]};
+                            f32x4{csum[qb][j][0], csum[qb][j][1], csum[qb][j][2], csum[qb][j][3]};
                 }
             }
         }
@@ -487,28 +473,23 @@ extern "C" int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2
     return MGX_OK;
 }
 
-extern "C" long mgx_gemm_nt_dact_colpart_floats(int M, int N) { return (long)((M + BM - 1) / BM) * 2 * N; }
+extern "C" long mgx_gemm_nt_dfac_colpart_floats(int M, int N) { return (long)((M + BM - 1) / BM) * 2 * N; }
 
-extern "C" int mgx_gemm_nt_dact_bf16(const void* A, const void* Bt, const void* pre, void* C, float* colpart, float* dbias,
-                                     int M, int N, int K, int lda, int ldb, int ldc, int act, float p_drop,
-                                     unsigned long long seed, void* stream) {
-    if (int rc = nt_check("mgx_gemm_nt_dact_bf16", A, Bt, C, M, N, K, lda, ldb, ldc)) return rc;
-    MGX_REQUIRE(pre, MGX_EINVAL, "mgx_gemm_nt_dact_bf16: null pre-activation");
-    MGX_REQUIRE(!dbias || colpart, MGX_EINVAL, "mgx_gemm_nt_dact_bf16: dbias needs the colpart workspace");
-    MGX_REQUIRE(act == MGX_ACT_GELU || act == MGX_ACT_RELU, MGX_EINVAL, "mgx_gemm_nt_dact_bf16: bad act %d", act);
-    MGX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, MGX_EINVAL, "mgx_gemm_nt_dact_bf16: p_drop=%f", p_drop);
-    NtArgs g{(const char*)A, (const char*)Bt, (bf16_t*)C, nullptr, nullptr, nullptr, (const bf16_t*)pre, colpart,
-             M, N, K, lda, ldb, ldc, p_drop, seed};
+extern "C" int mgx_gemm_nt_dfac_bf16(const void* A, const void* Bt, const void* fac, void* C, float* colpart, float* dbias,
+                                     int M, int N, int K, int lda, int ldb, int ldc, void* stream) {
+    if (int rc = nt_check("mgx_gemm_nt_dfac_bf16", A, Bt, C, M, N, K, lda, ldb, ldc)) return rc;
+    MGX_REQUIRE(fac, MGX_EINVAL, "mgx_gemm_nt_dfac_bf16: null derivative factor");
+    MGX_REQUIRE(!dbias || colpart, MGX_EINVAL, "mgx_gemm_nt_dfac_bf16: dbias needs the colpart workspace");
+    NtArgs g{(const char*)A, (const char*)Bt, (bf16_t*)C, nullptr, nullptr, nullptr, (const bf16_t*)fac, colpart,
+             M, N, K, lda, ldb, ldc, 0.f, 0ull};
     const long nblk = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    const bool drop = p_drop > 0.f;
-    if (act == MGX_ACT_GELU) { if (drop) NT_LAUNCH(EPI_DACT, MGX_ACT_GELU, true); else NT_LAUNCH(EPI_DACT, MGX_ACT_GELU, false); }
-    else { if (drop) NT_LAUNCH(EPI_DACT, MGX_ACT_RELU, true); else NT_LAUNCH(EPI_DACT, MGX_ACT_RELU, false); }
-    MGX_CHECK_LAUNCH("gemm_nt_dact");
+    NT_LAUNCH(EPI_DFAC, 0, false);
+    MGX_CHECK_LAUNCH("gemm_nt_dfac");
     if (dbias) {
         const int rows = 2 * ((M + BM - 1) / BM);
         hipLaunchKernelGGL(nt_colpart_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, (hipStream_t)stream, colpart,
                            dbias, rows, N);
-        MGX_CHECK_LAUNCH("gemm_nt_dact_reduce");
+        MGX_CHECK_LAUNCH("gemm_nt_dfac_reduce");
     }
     return MGX_OK;
 }

@@ -247,7 +247,8 @@ def bias_act_bwd(dh, pre, act="gelu", p_drop=0.0, seed=0):
 # bf16 MFMA GEMMs
 # ---------------------------------------------------------------------------
 def gemm_nt(a, bt, bias=None, res=None, act=None, p_drop=0.0, seed=0):
-    """C = a[M,K] @ bt[N,K]^T (+ bias) (+ res); with act: returns (pre, dropout(act(pre)))."""
+    """C = a[M,K] @ bt[N,K]^T (+ bias) (+ res); with act: returns (fac, dropout(act(pre))) where pre is the
+    bf16-rounded C and fac = act'(pre) * mask/(1-p) is what gemm_nt_dfac multiplies by in the backward."""
     _need(a, "a", torch.bfloat16)
     _need(bt, "bt", torch.bfloat16)
     M, K = a.shape
@@ -272,23 +273,24 @@ def gemm_nt(a, bt, bias=None, res=None, act=None, p_drop=0.0, seed=0):
     return c if act is None else (c, c2)
 
 
-def gemm_nt_dact(dy, bt, pre, act, p_drop=0.0, seed=0):
+def gemm_nt_dfac(dy, bt, fac):
     """Backward through `dropout(act(pre))` fused into the dgrad GEMM that produces its incoming gradient:
-    dpre[M,N] = (dy[M,K] @ bt[N,K]^T) * mask/(1-p) * act'(pre), and dbias[N] = dpre.sum(0) in fp32 (the kernel leaves
-    per-row-tile partial sums, reduced here in a fixed order).  Replaces one GEMM output + one bias_act_bwd pass."""
+    dpre[M,N] = (dy[M,K] @ bt[N,K]^T) * fac, with fac = act'(pre) * mask/(1-p) as gemm_nt(..., act=...) left it, and
+    dbias[N] = dpre.sum(0) in fp32 (per-row-tile partial sums, reduced by the library in a fixed order).  Replaces one
+    GEMM output + one bias_act_bwd pass."""
     _need(dy, "dy", torch.bfloat16)
     _need(bt, "bt", torch.bfloat16)
-    _need(pre, "pre", torch.bfloat16)
+    _need(fac, "fac", torch.bfloat16)
     M, K = dy.shape
     N, K2 = bt.shape
-    if K != K2 or K % 64 or N % 8 or pre.shape != (M, N):
-        raise ValueError(f"gemm_nt_dact: dy {tuple(dy.shape)} bt {tuple(bt.shape)} pre {tuple(pre.shape)}")
+    if K != K2 or K % 64 or N % 8 or fac.shape != (M, N):
+        raise ValueError(f"gemm_nt_dfac: dy {tuple(dy.shape)} bt {tuple(bt.shape)} fac {tuple(fac.shape)}")
     c = torch.empty(M, N, dtype=torch.bfloat16, device=dy.device)
-    part = torch.empty(int(lib.mgx_gemm_nt_dact_colpart_floats(M, N)), dtype=torch.float32, device=dy.device)
+    part = torch.empty(int(lib.mgx_gemm_nt_dfac_colpart_floats(M, N)), dtype=torch.float32, device=dy.device)
     dbias = torch.empty(N, dtype=torch.float32, device=dy.device)
     with _timed("gemm_nt", 2.0 * M * N * K):
-        check(lib.mgx_gemm_nt_dact_bf16(_p(dy), _p(bt), _p(pre), _p(c), _p(part), _p(dbias), M, N, K, K, K, N, _ACT[act],
-                                        float(p_drop), seed, _stream()), "mgx_gemm_nt_dact_bf16")
+        check(lib.mgx_gemm_nt_dfac_bf16(_p(dy), _p(bt), _p(fac), _p(c), _p(part), _p(dbias), M, N, K, K, K, N, _stream()),
+              "mgx_gemm_nt_dfac_bf16")
     return c, dbias
 
 
@@ -636,9 +638,9 @@ class _DecoderBlock(torch.autograd.Function):
         pr = gemm_nt(a2, W.wp_t, W.m_bp) if mfma else torch.addmm(W.bp, a2, W.wp)
         h1, z1, mean1, rstd1 = ln_residual_fwd(pr, x2, W.m_g1, W.m_be1, eps, p, seed1)
         if mfma:
-            # bias + activation + dropout in the up-projection's epilogue (two outputs: pre-activation for the backward,
-            # activated for linear2).  A/B in the step on one box: 20.48 ms against 20.64 ms with the separate
-            # HBM-bound bias_act_fwd pass.
+            # bias + activation + dropout in the up-projection's epilogue (two outputs: the activated tensor for
+            # linear2 and, in the slot of the pre-activation, the derivative factor act'(pre) * mask/(1-p) the
+            # backward multiplies by).
             pre, hact = gemm_nt(h1, W.w1, W.m_b1, act=act, p_drop=p, seed=seed2)
             v = gemm_nt(hact, W.w2, W.m_b2)
         else:
@@ -662,7 +664,7 @@ class _DecoderBlock(torch.autograd.Function):
         dz2, _, dg2, dbe2, db2 = ln_residual_bwd(dh2, None, z2, mean2, rstd2, W.m_g2, want_dsum=True)
         if mfma:
             dw2 = gemm_tn(dz2, hact)                                                    # [d, ff]
-            dpre, db1 = gemm_nt_dact(dz2, W.w2_t, pre, act, p, seed2)                   # dz2 @ w2 through act' (+ db1)
+            dpre, db1 = gemm_nt_dfac(dz2, W.w2_t, pre)                                  # dz2 @ w2 through act' (+ db1)
             dw1 = gemm_tn(dpre, h1)                                                     # [ff, d]
             dh1 = gemm_nt(dpre, W.w1_t)                                                 # [T, d]
         else:

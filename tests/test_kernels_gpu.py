@@ -539,9 +539,12 @@ def test_gemm_nt(M, N, K, epi):
     if act is None:
         assert gu.rel_err(out.float(), ref) < 1e-2
     else:
-        pre, h = out
-        assert gu.rel_err(pre.float(), ref) < 1e-2
-        assert gu.rel_err(h.float(), O._ACT[act](pre.float().cpu())) < 1e-2
+        fac, h = out                                  # derivative factor (for the backward) and activated output
+        pre = ref.bfloat16().float().requires_grad_(True)
+        y = O._ACT[act](pre)
+        y.backward(torch.ones_like(y))
+        assert gu.rel_err(h.float(), y.detach()) < 1e-2
+        assert gu.rel_err(fac.float(), pre.grad) < 1e-2
 
 
 def test_gemm_nt_exact_integers():
@@ -557,14 +560,18 @@ def test_gemm_nt_exact_integers():
 
 
 def test_gemm_nt_dropout_matches_bias_act_mask():
-    """The fused epilogue drops exactly the elements mgx_bias_act_bwd regenerates from (seed, index)."""
+    """The fused epilogue drops exactly the elements mgx_bias_act_bwd regenerates from (seed, index), in the activated
+    output and in the derivative factor alike."""
     ops = _ops()
     M, N, K, p, seed = 256, 512, 64, 0.25, 987654321
     a = torch.ones(M, K).bfloat16().cuda()
     bt = (torch.ones(N, K) / K).bfloat16().cuda()
-    pre, h = ops.gemm_nt(a, bt, torch.zeros(N).cuda(), None, "relu", p, seed)
+    fac, h = ops.gemm_nt(a, bt, torch.zeros(N).cuda(), None, "relu", p, seed)
     kept = h != 0
     assert abs(float(kept.float().mean()) - (1 - p)) < 0.02
+    assert torch.equal(fac != 0, kept)
+    assert torch.equal(fac[kept], torch.full_like(fac[kept], 1 / (1 - p)))
+    pre = torch.ones(M, N).bfloat16().cuda()
     dpre, _ = ops.bias_act_bwd(torch.ones(M, N).bfloat16().cuda(), pre, "relu", p, seed)
     assert torch.equal(dpre != 0, kept)
 
@@ -698,31 +705,41 @@ def test_embedding_gemm_backward(V, d, T):
 @pytest.mark.parametrize("M,N,K", [(512, 512, 128), (300, 264, 192), (1024, 4096, 1024)])
 @pytest.mark.parametrize("act", ["gelu", "relu"])
 @pytest.mark.parametrize("p_drop", [0.0, 0.25])
-def test_gemm_nt_dact(M, N, K, act, p_drop):
-    """dgrad GEMM with the activation-backward epilogue == GEMM (bf16 output) followed by mgx_bias_act_bwd: same
-    rounding points, same dropout mask; the bias gradient equals the column sums of the rounded result."""
+def test_gemm_nt_dfac(M, N, K, act, p_drop):
+    """linear1 forward with the activation epilogue (derivative factor saved) + the dgrad GEMM that multiplies by it
+    == plain GEMMs with mgx_bias_act_fwd / mgx_bias_act_bwd around them: same dropout mask, same activated output;
+    the bias gradient equals the column sums of the rounded result."""
     ops = _ops()
     g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16().cuda()
+    w1 = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().cuda()
+    b1 = torch.randn(N, generator=g).cuda()
     dy = torch.randn(M, K, generator=g).bfloat16().cuda()
     wt = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().cuda()
-    pre = torch.randn(M, N, generator=g).bfloat16().cuda()
     seed = 4242
-    dpre, db = ops.gemm_nt_dact(dy, wt, pre, act, p_drop, seed)
+    fac, h = ops.gemm_nt(x, w1, b1, None, act, p_drop, seed)
+    dpre, db = ops.gemm_nt_dfac(dy, wt, fac)
+    # the unfused chain on the same kernels' plain epilogues
+    pre = ops.gemm_nt(x, w1, b1)
+    _, h_want = ops.bias_act_fwd(pre, None, act, p_drop, seed)
     dact = ops.gemm_nt(dy, wt)
     want, want_db = ops.bias_act_bwd(dact, pre, act, p_drop, seed)
-    assert gu.rel_err(dpre.float(), want.float()) < 1e-2          # bf16 rounding of act' (two formulas of the same function)
+    assert gu.rel_err(h.float(), h_want.float()) < 2e-3            # two formulas of the same erf
+    assert torch.equal(h == 0, h_want == 0) or float(((h == 0) != (h_want == 0)).float().mean()) < 1e-3
+    assert gu.rel_err(dpre.float(), want.float()) < 1e-2          # bf16 rounding of act' and of the GEMM result
     assert float((dpre.float() - want.float()).abs().max()) <= 0.02 * float(want.float().abs().max())
     assert gu.rel_err(db, dpre.float().sum(0)) < 1e-4
     assert gu.rel_err(db, want_db) < 1e-2
     if p_drop > 0:                                                # identical keep mask
         assert torch.equal(dpre == 0, want == 0) or float(((dpre == 0) != (want == 0)).float().mean()) < 1e-3
     # against the oracle formula in fp32
-    x = pre.float().cpu().requires_grad_(True)
-    y = torch.nn.functional.gelu(x) if act == "gelu" else torch.relu(x)
+    xx = pre.float().cpu().requires_grad_(True)
+    y = torch.nn.functional.gelu(xx) if act == "gelu" else torch.relu(xx)
     y.backward(torch.ones_like(y))
     if p_drop == 0:
-        ref = dact.float().cpu() * x.grad
+        ref = dact.float().cpu() * xx.grad
         assert gu.rel_err(dpre.float(), ref) < BF16_TOL
+        assert gu.rel_err(h.float(), y.detach()) < BF16_TOL
 
 
 def test_embed_cat_matches_three_gathers():

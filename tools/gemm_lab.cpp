@@ -13,9 +13,8 @@
 extern "C" {
 int mgx_gemm_nt_bf16(const void*, const void*, void*, void*, const float*, const void*, int, int, int, int, int, int, int,
                      float, unsigned long long, void*);
-int mgx_gemm_nt_dact_bf16(const void*, const void*, const void*, void*, float*, float*, int, int, int, int, int, int, int, float,
-                          unsigned long long, void*);
-long mgx_gemm_nt_dact_colpart_floats(int, int);
+int mgx_gemm_nt_dfac_bf16(const void*, const void*, const void*, void*, float*, float*, int, int, int, int, int, int, void*);
+long mgx_gemm_nt_dfac_colpart_floats(int, int);
 long mgx_gemm_tn_workspace_floats(int, int, int, int*);
 int mgx_gemm_tn_bf16(const void*, const void*, void*, float*, int, int, int, int, int, int, void*);
 const char* mgx_last_error_string(void);
@@ -106,7 +105,7 @@ static void run_nt(int M, int N, int K, int rounds, int reps) {
     int* rows;
     bf16_t* pre;
     CK(hipMalloc(&pre, (size_t)M * N * 2));
-    CK(hipMalloc(&colpart, (size_t)mgx_gemm_nt_dact_colpart_floats(M, N) * 4));
+    CK(hipMalloc(&colpart, (size_t)mgx_gemm_nt_dfac_colpart_floats(M, N) * 4));
     fill_kernel<<<1024, 256>>>(pre, (long)M * N, 7u);
     CK(hipMalloc(&A, (size_t)M * K * 2));
     CK(hipMalloc(&Bt, (size_t)N * K * 2));
@@ -130,15 +129,15 @@ static void run_nt(int M, int N, int K, int rounds, int reps) {
     std::vector<float> href((size_t)NR * N);
     CK(hipMemcpy(href.data(), ref, href.size() * 4, hipMemcpyDeviceToHost));
 
-    std::vector<Variant> vs = {{"nt_bias", 3}, {"nt_dact_gelu_drop", 5}, {"nt_dact_gelu", 6}, {"nt_dact_relu", 7}, {"nt_dact_relu_nocolsum", 8}, {"nt_res", 9}};
+    std::vector<Variant> vs = {{"nt_bias", 3}, {"nt_act_gelu_drop", 4}, {"nt_act_gelu", 6}, {"nt_act_relu", 7}, {"nt_dfac", 5}, {"nt_dfac_nocolsum", 8}, {"nt_res", 9}};
     auto launch = [&](const Variant& v) -> int {
         switch (v.kind) {
             case 3: return mgx_gemm_nt_bf16(A, Bt, C, nullptr, bias, nullptr, M, N, K, K, K, N, -1, 0.f, 0, nullptr);
-            case 5: return mgx_gemm_nt_dact_bf16(A, Bt, pre, C, colpart, nullptr, M, N, K, K, K, N, 0, 0.1f, 1234, nullptr);
-            case 8: return mgx_gemm_nt_dact_bf16(A, Bt, pre, C, nullptr, nullptr, M, N, K, K, K, N, 1, 0.f, 1234, nullptr);
+            case 5: return mgx_gemm_nt_dfac_bf16(A, Bt, pre, C, colpart, nullptr, M, N, K, K, K, N, nullptr);
+            case 8: return mgx_gemm_nt_dfac_bf16(A, Bt, pre, C, nullptr, nullptr, M, N, K, K, K, N, nullptr);
             case 9: return mgx_gemm_nt_bf16(A, Bt, C, nullptr, bias, pre, M, N, K, K, K, N, -1, 0.f, 0, nullptr);
-            case 7: return mgx_gemm_nt_dact_bf16(A, Bt, pre, C, colpart, nullptr, M, N, K, K, K, N, 1, 0.f, 1234, nullptr);
-            case 6: return mgx_gemm_nt_dact_bf16(A, Bt, pre, C, colpart, nullptr, M, N, K, K, K, N, 0, 0.f, 1234, nullptr);
+            case 7: return mgx_gemm_nt_bf16(A, Bt, C, C2, bias, nullptr, M, N, K, K, K, N, 1, 0.f, 1234, nullptr);
+            case 6: return mgx_gemm_nt_bf16(A, Bt, C, C2, bias, nullptr, M, N, K, K, K, N, 0, 0.f, 1234, nullptr);
             default: return mgx_gemm_nt_bf16(A, Bt, C, C2, bias, nullptr, M, N, K, K, K, N, 0, 0.1f, 1234, nullptr);
         }
     };
