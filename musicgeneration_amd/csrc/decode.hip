@@ -241,8 +241,10 @@ __global__ __launch_bounds__(NW * 64, 4) void decode_attn_bf16_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = min(jb + u * RPL + sub, lastc);
-            kcur[u] = *reinterpret_cast<const u32x4*>(kb + (long)j * DH);
-            vcur[u] = *reinterpret_cast<const u32x4*>(vb + (long)j * DH);
+            // non-temporal: every cache row is read once per step, and 3.3 GB of them per step would otherwise push the
+            // 151 MB of weights out of the Infinity Cache (5.6 -> 6.4 TB/s at context 4096, step 0.896 -> 0.840 ms)
+            kcur[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)j * DH));
+            vcur[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)j * DH));
         }
     };
     auto load_new = [&]() {
