@@ -26,6 +26,7 @@ PROTOTYPES = {
     "mgx_alibi_attn_bwd_workspace_floats": (_l, [_i, _i, _i]),
     "mgx_alibi_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mgx_rel_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mgx_rel_attn_bwd_workspace_floats": (_l, [_i, _i, _i, _i, _i, _i]),
     "mgx_rel_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mgx_ln_residual_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _f, _u64, _i, _vp]),
     "mgx_ln_bwd_partial_rows": (_i, []),

@@ -77,9 +77,17 @@ extern "C" int mgx_rel_attn_fwd(const void* qkv, const void* E, void* out, float
     return mgx_attn_fwd_generic(1, qkv, nullptr, E, out, lse, B, S, H, dh, max_seq, dtype, (hipStream_t)stream);
 }
 
+long mgx_rel_bwd_mfma_workspace_floats(int B, int S, int H, int dh);     // attn_rel_mfma.hip
+extern "C" long mgx_rel_attn_bwd_workspace_floats(int B, int S, int H, int dh, int max_seq, int dtype) {
+    const bool generic = take_generic_flag(dtype);
+    if (!generic && mgx_attn_mfma_supported(1, dh, dtype, S, H, max_seq, true)) return mgx_rel_bwd_mfma_workspace_floats(B, S, H, dh);
+    return (long)B * H * S;
+}
+
 extern "C" int mgx_rel_attn_bwd(const void* dout, const void* qkv, const void* out, const float* lse, const void* E,
-                                void* dqkv, float* dE, float* delta, int B, int S, int H, int dh, int max_seq,
+                                void* dqkv, float* dE, float* workspace, int B, int S, int H, int dh, int max_seq,
                                 int dtype, void* stream) {
+    float* const delta = workspace;
     const bool g_force_generic = take_generic_flag(dtype);
     MGX_REQUIRE(dout && qkv && out && lse && E && dqkv && dE && delta, MGX_EINVAL, "mgx_rel_attn_bwd: null pointer");
     int rc = mgx_check_attn_shape("mgx_rel_attn_bwd", B, S, H, dh, dtype);

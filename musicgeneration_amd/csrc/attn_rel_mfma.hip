@@ -14,15 +14,15 @@
 // feeds dQ += dG.Er.  Nothing S x S reaches HBM.
 //
 // Orientation and staging are those of attn_mfma.hip (query on the lane for forward and dQ, key
-// on the lane for dK/dV).  dE has its own kernel (distance on the lane): a workgroup owns a band
-// of distances and walks down the diagonal band of the score matrix, so the dE accumulators stay
-// in registers for the whole launch: no atomics, bitwise reproducible.
+// on the lane for dK/dV).  dE = sum_i dG[i, r] q_i: the dQ kernel, which forms dG in distance
+// coordinates for its own second term, also stores it (bf16 blocks), and a batched causal TN GEMM
+// over those blocks (gemm_tn.hip, MODE 1) + a fixed-order sum over the batch give the table's
+// gradient: no atomics, bitwise reproducible, no recomputation of S / dP for dE.
 #include "attn_mfma_common.h"
 
 namespace {
 
 constexpr int REL_NW = 4;        // waves (x 32 rows) per workgroup
-constexpr int REL_DE_NW = 2;     // dE kernel: 64 distances per band x 2 query-half groups = 4 waves; bands paired
 constexpr int SKS = 68;          // ring row stride in floats (272 B: 16-byte reads of 16 consecutive lanes spread over all banks)
 
 // ---- the skew ring (query-on-lane kernels) ----------------------------------------------------
@@ -259,7 +259,7 @@ template <int DH, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void rel_bwd_dq_mfma_kernel(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
     const float* __restrict__ delta, const bf16_t* __restrict__ E, const bf16_t* __restrict__ ErT,
-    bf16_t* __restrict__ dqkv, int S, int H, int M, int Mp, float c, float scale) {
+    bf16_t* __restrict__ dqkv, char* __restrict__ dg, int nrb, int S, int H, int M, int Mp, float c, float scale) {
     constexpr int NT = 64 * NW, QB = 32 * NW, TB = Img<DH>::TILE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -305,9 +305,20 @@ __global__ __launch_bounds__(64 * NW, 2) void rel_bwd_dq_mfma_kernel(
         if (Rb >= 32) load_er_rows<DH>(ef, Eh, M, Rb - 32, l31, h5);
         ring_put_g(ring, g, Rb, l31, h5);
     };
+    // dG of this wave's 32 queries goes to HBM block by block for the dE GEMM (gemm_tn.hip, MODE 1): 2 KiB blocks
+    // [query unit][distance block][2 distance halves][32 queries][16 distances]; the MFMA operand of dQ += ErT . dG^T
+    // (8 consecutive distances of the lane's query) is the 16-byte piece as it stands.  That GEMM walks 256-distance
+    // tiles and reads, for the units inside a tile's own 256 queries, the blocks above the diagonal, which nobody
+    // computes: zeros, written here.
+    char* const dgp = dg + ((((long)b * H + h) * nrb + (qw0 >> 5)) * nrb << 11) + 32 * l31 + 16 * h5;
     if (qw0 < S) {
         load_er_rows<DH>(ef, Eh, M, qw0, l31, h5);
         g_block(qw0);
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int rb = (qw0 >> 5) + 1; rb <= min((qw0 >> 5) | 7, nrb - 1); ++rb) {
+            *reinterpret_cast<bf16x8*>(dgp + ((long)rb << 11)) = z;
+            *reinterpret_cast<bf16x8*>(dgp + ((long)rb << 11) + 1024) = z;
+        }
     }
 
     const int kmax = min(q0 + QB, S);
@@ -386,6 +397,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rel_bwd_dq_mfma_kernel(
                         const float v = row[(r - l31 - 1) & 63];
                         dgf[e] = (bf16_t)((r > qi) ? 0.f : v);     // r > i: key index below 0, never written
                     }
+                    *reinterpret_cast<bf16x8*>(dgp + ((long)(R0 >> 5) << 11) + 1024 * s2) = dgf;
 #pragma unroll
                     for (int d = 0; d < DH / 32; ++d)
                         dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(etf[s2][d], dgf, dq[d], 0, 0, 0);
@@ -594,234 +606,24 @@ __global__ __launch_bounds__(64 * NW, (DH == 128 ? 1 : 2)) void rel_bwd_dkv_mfma
     }
 }
 
-// dE: distance on the lane.  A workgroup owns 32*NW distances of one head and walks, for every
-// batch element, down the band of the score matrix those distances select: for the 32-query block
-// at I0 the keys are j = i - r, two 32-key blocks starting at JB - 32 and JB = I0 - rw0.
-//   S = Q.K^T, dP = dO.V^T on those key blocks -> skew to distance coordinates
-//   W = skew(S) + Q.Er^T - lse   P = exp2   dW = P*(skew(dP) - delta)*scale
-//   dEr^T[d, r] += Q^T . dW      (accumulators live in registers for the whole launch)
-template <int DH, int NWD>
-__device__ __forceinline__ void rel_de_band(
-    char* smem, const int rb0, const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qkv,
-    const float* __restrict__ lse, const float* __restrict__ delta, const bf16_t* __restrict__ E,
-    float* __restrict__ dE, int B, int S, int H, int M, float c, float scale) {
-    constexpr int NW = 2 * NWD, NT = 64 * NW, TB = Img<DH>::TILE_BYTES;
-    static_assert(NWD % 2 == 0, "a band must cover whole 64-key tiles");
-    // Keys/values of the band: staged through a 3-slot LDS ring of 64-key tiles (tiles T-1, T in use,
-    // T+1 being filled) when it fits (dh 64); at dh 128 the ring would exceed 160 KB and each wave
-    // fetches its two 32-key operand blocks straight from global memory instead.
-    constexpr bool KVL = DH == 64;
-    char* kvring = smem + 4 * TB;
-    float* stats = reinterpret_cast<float*>(smem + (KVL ? 10 : 4) * TB);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int l31 = lane & 31, h5 = lane >> 5;
-    float* skew = stats + 4 * 64 + w * 32 * BKS;
-    const int rw0 = rb0 + 32 * (w % NWD);
-    const int tb = w / NWD;                               // which 32-query half of every staged tile this wave takes
-    const int h = blockIdx.x;
-    const unsigned rs = 3u * H * DH;
-    const bf16_t* Eh = E + (long)h * M * DH;
-    const LaneAddr<DH> la(lane);
-    const int r = rw0 + l31;
-    const float inv_c = 1.f / c;
-
-    bf16x8 erf[DH / 16];
-    load_er_rows<DH>(erf, Eh, M, rw0, l31, h5);
-    f32x16 de[DH / 32];
-#pragma unroll
-    for (int d = 0; d < DH / 32; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) de[d][e] = 0.f;
-
-    const int t0 = rb0 / 64;
-    const int ntiles = (S + 63) / 64;
-    for (int b = 0; b < B && rb0 < S; ++b) {
-        const bf16_t* base = qkv + (long)b * S * rs + (long)h * DH;
-        const bf16_t* kp = base + (long)H * DH;
-        const bf16_t* vp = base + 2L * H * DH;
-        const bf16_t* gp = dout + (long)b * S * H * DH + (long)h * DH;
-        const float* lse_bh = lse + ((long)b * H + h) * S;
-        const float* delta_bh = delta + ((long)b * H + h) * S;
-        TileRegs<DH, NT> qr, gr, kr, vr;
-        float r_lse = 0.f, r_delta = 0.f;
-        // query tile at i0 travels with key tile at i0 - rb0 (the keys at distance rb0.. below it)
-        auto load_tile = [&](int i0) {
-            tile_load<DH, NT>(qr, base, rs, i0, S, tid);
-            tile_load<DH, NT>(gr, gp, (unsigned)(H * DH), i0, S, tid);
-            if (KVL) {
-                tile_load<DH, NT>(kr, kp, rs, i0 - rb0, S, tid);
-                tile_load<DH, NT>(vr, vp, rs, i0 - rb0, S, tid);
-            }
-            if (tid < 64 && i0 + tid < S) {
-                r_lse = lse_bh[i0 + tid];
-                r_delta = delta_bh[i0 + tid];
-            }
-        };
-        auto store_tile = [&](int i0, int buf) {
-            tile_store<DH, NT>(qr, smem + buf * 2 * TB, tid);
-            tile_store<DH, NT>(gr, smem + buf * 2 * TB + TB, tid);
-            if (KVL) {
-                char* slot = kvring + (((i0 - rb0) >> 6) % 3) * 2 * TB;
-                tile_store<DH, NT>(kr, slot, tid);
-                tile_store<DH, NT>(vr, slot + TB, tid);
-            }
-            if (tid < 64) {
-                const bool ok = i0 + tid < S;
-                stats[buf * 128 + tid] = ok ? -(r_lse * LOG2E * inv_c) : -INFINITY;
-                stats[buf * 128 + 64 + tid] = ok ? -r_delta : 0.f;
-            }
-        };
-        bf16x8 ka[DH / 16], kb[DH / 16], va[DH / 16], vb[DH / 16];      // !KVL: operand blocks from global
-        auto load_kv = [&](int J) {                        // rows J-32.. (lower block) and J.. (upper block)
-            const int ra = min(max(J - 32 + l31, 0), S - 1), rb = min(max(J + l31, 0), S - 1);
-#pragma unroll
-            for (int ks = 0; ks < DH / 16; ++ks) {
-                ka[ks] = *reinterpret_cast<const bf16x8*>(kp + (long)ra * rs + 16 * ks + 8 * h5);
-                va[ks] = *reinterpret_cast<const bf16x8*>(vp + (long)ra * rs + 16 * ks + 8 * h5);
-                kb[ks] = *reinterpret_cast<const bf16x8*>(kp + (long)rb * rs + 16 * ks + 8 * h5);
-                vb[ks] = *reinterpret_cast<const bf16x8*>(vp + (long)rb * rs + 16 * ks + 8 * h5);
-            }
-        };
-        // the wave's first block is the first I0 = 64 t + 32 tb >= rw0
-        if (!KVL) load_kv(((max(rw0 - 32 * tb, 0) + 63) / 64) * 64 + 32 * tb - rw0);
-        __syncthreads();                                   // previous batch element's tiles are consumed
-        load_tile(t0 * 64);
-        store_tile(t0 * 64, 0);
-        if (t0 + 1 < ntiles) load_tile(t0 * 64 + 64);
-        __syncthreads();
-        for (int t = t0; t < ntiles; ++t) {
-            const int i0 = t * 64;
-            const int buf = (t - t0) & 1;
-            const char* Qs = smem + buf * 2 * TB;
-            const char* Gs = Qs + TB;
-            const float* Ls = stats + buf * 128;
-            const float* Dn = Ls + 64;
-            if (t + 1 < ntiles) store_tile(i0 + 64, buf ^ 1);
-            if (t + 2 < ntiles) load_tile(i0 + 128);
-            if (rw0 < S) {                                     // wave-uniform
-                {
-                    const int JB = i0 + 32 * tb - rw0;         // key of (query block start, distance rw0)
-                    if (JB < 0) goto next_tile;
-                    bf16x8 af[DH / 16], gfr[DH / 16];
-#pragma unroll
-                    for (int ks = 0; ks < DH / 16; ++ks) {
-                        af[ks] = lds_read16(Qs + la.row_read(tb, ks));
-                        gfr[ks] = lds_read16(Gs + la.row_read(tb, ks));
-                    }
-                    // upper key block [JB, JB+32) and lower [JB-32, JB): halves of ring tiles
-                    const char* Kb = kvring + ((JB >> 6) % 3) * 2 * TB;
-                    const int hb = (JB >> 5) & 1;
-                    const int JA = max(JB - 32, 0);
-                    const char* Ka = kvring + ((JA >> 6) % 3) * 2 * TB;
-                    const int ha = (JA >> 5) & 1;
-                    f32x16 sc, dp;
-                    {
-                        f32x16 sa, sb;
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) sa[e] = sb[e] = 0.f;
-#pragma unroll
-                        for (int ks = 0; ks < DH / 16; ++ks) {
-                            sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], KVL ? lds_read16(Kb + la.row_read(hb, ks)) : kb[ks], sb, 0, 0, 0);
-                            if (JB > 0) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], KVL ? lds_read16(Ka + la.row_read(ha, ks)) : ka[ks], sa, 0, 0, 0);
-                        }
-                        band_put(skew, sa, 0, l31, h5);
-                        band_put(skew, sb, 1, l31, h5);
-                        band_get(skew, sc, l31, h5);
-                    }
-                    {
-                        f32x16 pa, pb;
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) pa[e] = pb[e] = 0.f;
-#pragma unroll
-                        for (int ks = 0; ks < DH / 16; ++ks) {
-                            pb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[ks], KVL ? lds_read16(Kb + TB + la.row_read(hb, ks)) : vb[ks], pb, 0, 0, 0);
-                            if (JB > 0) pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[ks], KVL ? lds_read16(Ka + TB + la.row_read(ha, ks)) : va[ks], pa, 0, 0, 0);
-                        }
-                        band_put(skew, pa, 0, l31, h5);
-                        band_put(skew, pb, 1, l31, h5);
-                        band_get(skew, dp, l31, h5);
-                    }
-                    if (!KVL) load_kv(JB + 64);                // this wave's next block (one tile further)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 lv = *reinterpret_cast<const f32x4*>(Ls + 32 * tb + 8 * g + 4 * h5);
-                        const f32x4 dn = *reinterpret_cast<const f32x4*>(Dn + 32 * tb + 8 * g + 4 * h5);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            sc[4 * g + k] += lv[k];
-                            dp[4 * g + k] += dn[k];
-                        }
-                    }
-#pragma unroll
-                    for (int ks = 0; ks < DH / 16; ++ks)
-                        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], erf[ks], sc, 0, 0, 0);
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int il = 8 * (e >> 2) + 4 * h5 + (e & 3);
-                        float p = fast_exp2(sc[e] * c);
-                        if (JB + il - l31 < 0) p = 0.f;        // key index below 0 (distance beyond the query)
-                        sc[e] = p * dp[e] * scale;
-                    }
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const bf16x8 dwf = pack8(sc, 8 * s2);
-#pragma unroll
-                        for (int d = 0; d < DH / 32; ++d) {
-                            const bf16x8 qt = lds_read_tr_pair(Qs + la.tr_read(tb, s2, 0, d), Qs + la.tr_read(tb, s2, 1, d));
-                            de[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, dwf, de[d], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        next_tile:
-            __syncthreads();
-        }
+// dE[h, M-1-r, :] = sum_b slab[b, h][r, :] for r < Mp (the distances a query can reach), zero for the rest of the
+// table; fixed summation order.  The slabs come from the dE GEMM over the stored dG blocks (gemm_tn.hip, MODE 1).
+__global__ __launch_bounds__(256) void rel_de_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dE, int B,
+                                                             int H, int M, int Mp, int dh) {
+    const long n4 = (long)H * M * dh / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n4) return;
+    const int per_row = dh / 4;
+    const int c4 = (int)(idx % per_row);
+    const long hr = idx / per_row;
+    const int row = (int)(hr % M), h = (int)(hr / M);
+    const int r = M - 1 - row;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (r < Mp) {
+        const float* p = slabs + ((long)h * Mp + r) * dh + 4 * c4;
+        for (int b = 0; b < B; ++b) s += *reinterpret_cast<const f32x4*>(p + (long)b * H * Mp * dh);
     }
-    // the two query-half groups hold partial sums of the same distances: add them in a fixed order
-    {
-        float* red = reinterpret_cast<float*>(smem) + (size_t)(w % NWD) * (DH / 32) * 16 * 64;
-        if (tb == 1) {
-#pragma unroll
-            for (int d = 0; d < DH / 32; ++d)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) red[(d * 16 + e) * 64 + lane] = de[d][e];
-        }
-        __syncthreads();
-        if (tb == 0) {
-#pragma unroll
-            for (int d = 0; d < DH / 32; ++d)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) de[d][e] += red[(d * 16 + e) * 64 + lane];
-        }
-    }
-    if (tb == 0 && r < M) {
-        float* op = dE + ((long)h * M + (M - 1 - r)) * DH;
-#pragma unroll
-        for (int d = 0; d < DH / 32; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 v;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = de[d][4 * g + k];
-                *reinterpret_cast<f32x4*>(op + 32 * d + 8 * g + 4 * h5) = v;
-            }
-    }
-}
-
-// Band y and band N-1-y have complementary lengths (S - r queries each): one workgroup takes both,
-// so every workgroup of the launch carries the same amount of work.
-template <int DH, int NWD>
-__global__ __launch_bounds__(128 * NWD, 1) void rel_bwd_de_mfma_kernel(
-    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
-    const float* __restrict__ delta, const bf16_t* __restrict__ E, float* __restrict__ dE, int B, int S, int H, int M,
-    int nbands, float c, float scale) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (Q, dO images), stats, NW skew buffers
-    const int y = blockIdx.y, y2 = nbands - 1 - y;
-    rel_de_band<DH, NWD>(smem, y * 32 * NWD, dout, qkv, lse, delta, E, dE, B, S, H, M, c, scale);
-    if (y2 > y) {
-        __syncthreads();
-        rel_de_band<DH, NWD>(smem, y2 * 32 * NWD, dout, qkv, lse, delta, E, dE, B, S, H, M, c, scale);
-    }
+    *reinterpret_cast<f32x4*>(dE + idx * 4) = s;
 }
 
 template <typename F>
@@ -853,16 +655,28 @@ int mgx_rel_fwd_mfma(const void* qkv, const void* E, void* out, float* lse, int 
 
 bool mgx_rel_bwd_mfma_ready() { return true; }
 
+// workspace of the backward, in floats: delta [B,H,S] | dE slabs [B*H][32 nrb][dh] | dG blocks [B*H][nrb][nrb] x 2 KiB
+long mgx_rel_bwd_mfma_workspace_floats(int B, int S, int H, int dh) {
+    const long nrb = (S + 31) / 32;
+    const long delta = ((long)B * H * S + 63) / 64 * 64;
+    return delta + (long)B * H * nrb * 32 * dh + (long)B * H * nrb * nrb * 512;
+}
+int mgx_rel_de_from_dg(const void* dg, const void* qkv, float* slabs, int B, int S, int H, int dh, int nrb, hipStream_t st);   // gemm_tn.hip
+
 namespace {
 template <int DH>
 int launch_rel_bwd(const void* dout, const void* qkv, const void* out, const float* lse, const void* E, void* dqkv,
-                   float* dE, float* delta, int B, int S, int H, int max_seq, hipStream_t st) {
+                   float* dE, float* ws, int B, int S, int H, int max_seq, hipStream_t st) {
     const float scale = 1.0f / sqrtf((float)DH);
     const float c = LOG2E * scale;
     constexpr int NW = REL_NW;
     const int M = max_seq, Mp = (M + 31) / 32 * 32;
+    const int nrb = (S + 31) / 32;
+    float* delta = ws;
+    float* slabs = ws + ((long)B * H * S + 63) / 64 * 64;
+    char* dg = reinterpret_cast<char*>(slabs + (long)B * H * nrb * 32 * DH);
     // the dE buffer (fp32 [H,M,DH]) holds the transposed bf16 copy of E (H*DH*Mp*2 bytes <= its size
-    // since Mp <= 2M) until the dE kernel, which runs last, overwrites it
+    // since Mp <= 2M) until the reduction of the dE slabs, which runs last, overwrites it
     bf16_t* ErT = reinterpret_cast<bf16_t*>(dE);
     const long n_t = (long)H * DH * Mp;
     hipLaunchKernelGGL(rel_ert_kernel, dim3((unsigned)((n_t + 255) / 256)), dim3(256), 0, st, (const bf16_t*)E, ErT, H, M,
@@ -881,16 +695,14 @@ int launch_rel_bwd(const void* dout, const void* qkv, const void* out, const flo
     allow_smem(rel_bwd_dq_mfma_kernel<DH, NW>, rel_fwd_smem<DH>(NW));
     hipLaunchKernelGGL((rel_bwd_dq_mfma_kernel<DH, NW>), grid, dim3(64 * NW), rel_fwd_smem<DH>(NW), st,
                        (const bf16_t*)dout, (const bf16_t*)qkv, lse, delta, (const bf16_t*)E, (const bf16_t*)ErT,
-                       (bf16_t*)dqkv, S, H, M, Mp, c, scale);
+                       (bf16_t*)dqkv, dg, nrb, S, H, M, Mp, c, scale);
     MGX_CHECK_LAUNCH("rel_bwd_dq_mfma");
-    constexpr int NWE = REL_DE_NW;
-    const int nbands = (M + 32 * NWE - 1) / (32 * NWE);
-    const size_t de_smem = (size_t)(DH == 64 ? 10 : 4) * Img<DH>::TILE_BYTES + 4 * 64 * sizeof(float) + (size_t)2 * NWE * 32 * BKS * sizeof(float);
-    dim3 gride(H, (nbands + 1) / 2);
-    allow_smem(rel_bwd_de_mfma_kernel<DH, NWE>, de_smem);
-    hipLaunchKernelGGL((rel_bwd_de_mfma_kernel<DH, NWE>), gride, dim3(128 * NWE), de_smem, st, (const bf16_t*)dout,
-                       (const bf16_t*)qkv, lse, delta, (const bf16_t*)E, dE, B, S, H, M, nbands, c, scale);
-    MGX_CHECK_LAUNCH("rel_bwd_de_mfma");
+    // dE: a batched, causal TN GEMM over the dG blocks (one slab per (b, h)), then the sum over b into the table
+    if (int rc = mgx_rel_de_from_dg(dg, qkv, slabs, B, S, H, DH, nrb, st)) return rc;
+    const long n4 = (long)H * M * DH / 4;
+    hipLaunchKernelGGL(rel_de_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, slabs, dE, B, H, M,
+                       nrb * 32, DH);
+    MGX_CHECK_LAUNCH("rel_de_reduce");
     return MGX_OK;
 }
 }  // namespace

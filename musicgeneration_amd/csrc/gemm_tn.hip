@@ -26,6 +26,10 @@ struct TnArgs {
     int M, N, K;
     int lda, ldb;
     int ksplit_len;          // K elements per split (multiple of 64)
+    // MODE 1 (dE of the skew relative attention from the dG blocks the dQ kernel stored, attn_rel_mfma.hip):
+    // A = blocked dG, B = the packed qkv (q third of b = 0, h = 0), C = fp32 slabs [B*H][M][N]; M = padded number
+    // of distances, N = dh, K = S (queries)
+    int bk_bh, bk_h, bk_nrb;   // B*H, H, 32-distance blocks per 32-query unit row
 };
 
 __device__ const bf16_t g_tn_zero16[8] = {};
@@ -80,7 +84,14 @@ __device__ __forceinline__ void static_for(F&& f) {
     } while (0)
 
 // TAIL: the split's K range may end inside a K tile (rows past the end are read from a block of zeros)
-template <bool TAIL>
+// MODE 0: weight gradients (split K, fp32 slabs).
+// MODE 1: dEr[b,h][r, :] = sum_i dG[b,h][i, r] . q[b,i,h, :] of the skew relative attention, from the dG blocks the dQ
+//   kernel stored: [32-query unit][32-distance block][2 distance halves][32 queries][16 distances] bf16, 2 KiB each,
+//   i.e. K-major in both operands (this kernel's form) with a blocked address map on the A side.  One workgroup per
+//   (b, h, 256-distance tile), longest K range first; the K range starts at the tile's first distance (r <= i);
+//   only the first dh columns of the block tile exist, so the two quadrants of the second B half tile are not
+//   computed; fp32 result rows go to the slab of (b, h), summed over b by rel_de_reduce_kernel (attn_rel_mfma.hip).
+template <bool TAIL, int MODE>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[2 * LDS_B];
     typedef __attribute__((address_space(3))) void lds_void;
@@ -92,22 +103,40 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs g) {
     // Workgroups that share an XCD (blockIdx % 8) take a contiguous run of (split, tile) pairs, the smaller tile
     // dimension fastest: the ~32 workgroups resident on one XCD cover a compact rectangle of tiles of ONE K split
     // and walk K together, so every A / B panel slice is fetched into that XCD's L2 once.
-    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM;
-    const int ntile = nbm * nbn;
-    const int wid = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = wid / ntile;
-    const int tile = wid - split * ntile;
-    int bm, bn;
-    if (nbm <= nbn) {
-        bn = tile / nbm;
-        bm = tile - bn * nbm;
+    int split = 0, m0, n0, kbeg, kend;
+    const char* Ab = g.A;
+    const char* Bb = g.B;
+    if constexpr (MODE == 0) {
+        const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM;
+        const int ntile = nbm * nbn;
+        const int wid = xcd_remap(blockIdx.x, gridDim.x);
+        split = wid / ntile;
+        const int tile = wid - split * ntile;
+        int bm, bn;
+        if (nbm <= nbn) {
+            bn = tile / nbm;
+            bm = tile - bn * nbm;
+        } else {
+            bm = tile / nbn;
+            bn = tile - bm * nbn;
+        }
+        m0 = bm * BM;
+        n0 = bn * BN;
+        kbeg = split * g.ksplit_len;
+        kend = min(g.K, kbeg + g.ksplit_len);
     } else {
-        bm = tile / nbn;
-        bn = tile - bm * nbn;
+        // dispatch order: every (b, h) of the tile row with the longest K range first; (b, h) % 8 = the XCD, the
+        // same for all of its tiles (its q rows stay in that XCD's L2)
+        const int ord = blockIdx.x / g.bk_bh, bh = blockIdx.x - ord * g.bk_bh;
+        m0 = ord * BM;
+        n0 = 0;
+        kbeg = m0;
+        kend = g.K;
+        split = bh;
+        const int b = bh / g.bk_h, h = bh - b * g.bk_h;
+        Ab += ((long)bh * g.bk_nrb + (kbeg >> 5)) * g.bk_nrb * 2048;
+        Bb += ((long)b * g.K * g.ldb + (long)h * g.N) * 2;
     }
-    const int m0 = bm * BM, n0 = bn * BN;
-    const int kbeg = split * g.ksplit_len;
-    const int kend = min(g.K, kbeg + g.ksplit_len);
     const int nk = (kend - kbeg + BK - 1) / BK;
 
     // ---- staging: half tile X = [64 k][128 columns]; piece 2w+i = k rows 8w.., 16-byte chunks 8i..8i+7
@@ -118,13 +147,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int ch = 8 * i + 4 * (lane >> 5) + ((lane & 3) ^ ((srow >> 2) & 3));
-            sa[X][i] = (unsigned)(((long)srow * g.lda + min(m0 + 128 * X + ch * 8, g.M - 8)) * 2);
+            if constexpr (MODE == 0) {
+                sa[X][i] = (unsigned)(((long)srow * g.lda + min(m0 + 128 * X + ch * 8, g.M - 8)) * 2);
+            } else {
+                // query row srow of the K tile: unit srow >> 5, row srow & 31 of the block; 8 distances of block m >> 5
+                const int m = min(m0 + 128 * X + ch * 8, g.M - 8);
+                sa[X][i] = (unsigned)((((srow >> 5) * g.bk_nrb + (m >> 5)) * 2048) + ((m >> 4) & 1) * 1024 +
+                                      (srow & 31) * 32 + (m & 15) * 2);
+            }
             sb[X][i] = (unsigned)(((long)srow * g.ldb + min(n0 + 128 * X + ch * 8, g.N - 8)) * 2);
         }
     char* const stage_base = smem + 2048 * w;
     auto stage_a = [&](int X, int d, int kt) {
         const int k0 = kbeg + min(kt, nk - 1) * BK;
-        const char* src = g.A + (long)k0 * g.lda * 2;
+        const char* src = MODE == 0 ? Ab + (long)k0 * g.lda * 2 : Ab + (long)((k0 - kbeg) >> 5) * g.bk_nrb * 2048;
         char* dst = stage_base + (2 * X + d) * HT;
         const char* p0 = src + sa[X][0];
         const char* p1 = src + sa[X][1];
@@ -134,11 +170,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs g) {
     };
     auto stage_b = [&](int X, int d, int kt) {
         const int k0 = kbeg + min(kt, nk - 1) * BK;
-        const char* src = g.B + (long)k0 * g.ldb * 2;
+        const char* src = Bb + (long)k0 * g.ldb * 2;
         char* dst = stage_base + LDS_B + (2 * X + d) * HT;
         const char* p0 = src + sb[X][0];
         const char* p1 = src + sb[X][1];
         if (TAIL && k0 + srow >= kend) p0 = p1 = (const char*)g_tn_zero16;
+        if (MODE == 1 && X == 1) p0 = p1 = (const char*)g_tn_zero16;   // no second B half tile: same instruction count, no traffic
         __builtin_amdgcn_global_load_lds((const void*)p0, (lds_void*)(dst), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const void*)p1, (lds_void*)(dst + 1024), 16, 0, 0);
     };
@@ -232,18 +269,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs g) {
         TN_LGKM0();
         TN_MMA(0, 0, b0);
         TN_BAR();
-        read_b(b1, I1{}, dtag);
+        if constexpr (MODE == 0) read_b(b1, I1{}, dtag);
         stage_a(1, d ^ 1, t + 1);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         TN_BAR();
         TN_LGKM0();
-        TN_MMA(0, 1, b1);
+        if constexpr (MODE == 0) TN_MMA(0, 1, b1);
         TN_BAR();
         read_a(I1{}, dtag);
         stage_a(0, d, t + 2);
         TN_BAR();
         TN_LGKM0();
-        TN_MMA(1, 1, b1);
+        if constexpr (MODE == 0) TN_MMA(1, 1, b1);
         TN_BAR();
         stage_b(0, d, t + 2);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -269,7 +306,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs g) {
             const int m = m0 + 128 * qa + 64 * wr + 16 * i + l15;
             if (m >= g.M) continue;
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
+            for (int qb = 0; qb < (MODE == 0 ? 2 : 1); ++qb)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int n = n0 + 128 * qb + 32 * wc + 16 * j + 4 * g4;
@@ -321,13 +358,13 @@ extern "C" int mgx_gemm_tn_bf16(const void* A, const void* B, void* C, float* wo
     mgx_gemm_tn_workspace_floats(M, N, K, &splits);
     int len = ((K + splits - 1) / splits + BK - 1) / BK * BK;
     splits = (K + len - 1) / len;
-    TnArgs g{(const char*)A, (const char*)B, workspace, M, N, K, lda, ldb, len};
+    TnArgs g{(const char*)A, (const char*)B, workspace, M, N, K, lda, ldb, len, 0, 0, 0};
     const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     hipStream_t st = (hipStream_t)stream;
     if (K % BK == 0)
-        hipLaunchKernelGGL((gemm_tn_kernel<false>), dim3((unsigned)(tiles * splits)), dim3(NTHREADS), 0, st, g);
+        hipLaunchKernelGGL((gemm_tn_kernel<false, 0>), dim3((unsigned)(tiles * splits)), dim3(NTHREADS), 0, st, g);
     else
-        hipLaunchKernelGGL((gemm_tn_kernel<true>), dim3((unsigned)(tiles * splits)), dim3(NTHREADS), 0, st, g);
+        hipLaunchKernelGGL((gemm_tn_kernel<true, 0>), dim3((unsigned)(tiles * splits)), dim3(NTHREADS), 0, st, g);
     MGX_CHECK_LAUNCH("gemm_tn");
     const long n = (long)M * N;
     long blocks = (n / 4 + 255) / 256;
@@ -337,5 +374,23 @@ extern "C" int mgx_gemm_tn_bf16(const void* A, const void* B, void* C, float* wo
     else
         hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, workspace, (bf16_t*)C, n, splits);
     MGX_CHECK_LAUNCH("splitk_reduce");
+    return MGX_OK;
+}
+
+// skew relative attention backward, dEr slabs from the dG blocks of rel_bwd_dq_mfma_kernel (attn_rel_mfma.hip).
+// dg: [B*H][nrb query units][nrb distance blocks] blocks of 2 KiB; slabs: [B*H][32 nrb][dh] fp32
+int mgx_rel_de_from_dg(const void* dg, const void* qkv, float* slabs, int B, int S, int H, int dh, int nrb, hipStream_t st) {
+    MGX_REQUIRE(dh == 64 || dh == 128, MGX_EUNSUPPORTED, "rel dE from dG: dh=%d", dh);
+    const int Mp = nrb * 32;
+    const int rs = 3 * H * dh;
+    MGX_REQUIRE(64L * rs < (1L << 30), MGX_EUNSUPPORTED, "rel dE from dG: row stride too large");
+    TnArgs g{(const char*)dg, (const char*)qkv, slabs, Mp, dh, S, 0, rs, 0, B * H, H, nrb};
+    const int nT = (min(Mp, (S + 31) / 32 * 32) + BM - 1) / BM;       // distance tiles that hold a distance <= S - 1
+    const unsigned grid = (unsigned)(B * H * nT);
+    if (S % BK == 0)
+        hipLaunchKernelGGL((gemm_tn_kernel<false, 1>), dim3(grid), dim3(NTHREADS), 0, st, g);
+    else
+        hipLaunchKernelGGL((gemm_tn_kernel<true, 1>), dim3(grid), dim3(NTHREADS), 0, st, g);
+    MGX_CHECK_LAUNCH("rel_de_from_dg");
     return MGX_OK;
 }

@@ -134,10 +134,11 @@ def rel_attn_bwd(dout, qkv, out, lse, E, n_heads: int, generic: bool = False):
     H, M, dh = E.shape
     dqkv = torch.empty_like(qkv)
     dE = torch.empty(H, M, dh, dtype=torch.float32, device=qkv.device)
-    delta = torch.empty_like(lse)
+    dt = _attn_dt(qkv, generic)
+    ws = torch.empty(int(lib.mgx_rel_attn_bwd_workspace_floats(B, S, H, dh, M, dt)), dtype=torch.float32, device=qkv.device)
     with _timed("rel_attn_bwd", 6.0 * B * H * S * S * dh):      # dV, dP, dQ (two terms), dK, dE at half the square
-        check(lib.mgx_rel_attn_bwd(_p(dout), _p(qkv), _p(out), _p(lse), _p(E), _p(dqkv), _p(dE), _p(delta), B, S, H, dh, M,
-                                   _attn_dt(qkv, generic), _stream()), "mgx_rel_attn_bwd")
+        check(lib.mgx_rel_attn_bwd(_p(dout), _p(qkv), _p(out), _p(lse), _p(E), _p(dqkv), _p(dE), _p(ws), B, S, H, dh, M,
+                                   dt, _stream()), "mgx_rel_attn_bwd")
     return dqkv, dE
 
 

@@ -156,7 +156,7 @@ def test_relative_attention(B, S, H, dh, M, dtype):
                                          (1, 384, 2, 64, 384), (1, 31, 1, 64, 32), (1, 129, 2, 128, 1024), (3, 200, 2, 64, 256), (5, 96, 1, 64, 128)])
 @pytest.mark.parametrize("force_generic", [False, True])
 def test_relative_attention_bf16_mfma(B, S, H, dh, M, force_generic):
-    """Skew relative attention on the MFMA path (ring skew through LDS, dE band kernel) and on the
+    """Skew relative attention on the MFMA path (ring skew through LDS, dE as a GEMM over the stored dG blocks) and on the
     generic path, against the oracle's pad/reshape skew in fp32 on the same bf16-rounded inputs."""
     ops = _ops()
     g = torch.Generator().manual_seed(S * 3 + dh + M)
