@@ -15,8 +15,8 @@ def per_launch(tag, ctr, pat, also=None):
 T, d, ff, L, Vp = 32768, 1024, 4096, 6, 640
 def nt(M, N, K, extra_mn=0):          # bf16 operands and output; extra_mn = further M x N bf16 streams (residual, pre-activation)
     return 2 * (M * K + N * K + M * N * (1 + extra_mn))
-fwd = nt(T, 3 * d, d) + nt(T, d, d, 1) + nt(T, ff, d) + nt(T, d, ff, 1)
-bwd = nt(T, ff, d, 1) + nt(T, d, ff) + nt(T, d, d) + nt(T, d, 3 * d)      # first one: dgrad + activation backward (reads pre)
+fwd = nt(T, 3 * d, d) + nt(T, d, d, 1) + nt(T, ff, d, 1) + nt(T, d, ff, 1)      # linear1 writes two outputs (activated, derivative factor)
+bwd = nt(T, ff, d, 1) + nt(T, d, ff) + nt(T, d, d) + nt(T, d, 3 * d)      # first one: dgrad x derivative factor (reads fac)
 nt_algo = (L * (fwd + bwd) + nt(T, Vp, d) + nt(T, d, Vp)) / (8 * L + 2)
 tn = lambda m, n: 2 * T * (m + n) + 4 * m * n                               # bf16 in, fp32 dW out
 tn_algo = (L * (tn(d, ff) + tn(ff, d) + tn(d, d) + tn(d, 3 * d)) + tn(d, Vp) + tn(Vp, d)) / (4 * L + 2)
