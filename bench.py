@@ -145,6 +145,108 @@ def cpu_baseline(steps=5, warmup=2):
                       f"'{model}' (os.cpu_count()={os.cpu_count()}, physical cores={phys})"}
 
 
+DEFAULT_SHAPES = {"train_unified": (16, 2048), "train_separated": (8, 1024), "train_relative": (8, 4096)}
+
+
+def bench_training(a, workload, B, S, steps, warmup, device, rank, world, force_dp):
+    """One training workload: `warmup` untimed steps, then exactly `steps` timed ones between barriers; returns the
+    record (tokens/s over all ranks, step time, roofline lines of the MFMA kernels from HIP-event pairs)."""
+    from musicgeneration_amd import ops
+    from musicgeneration_amd.optim import FusedAdamW
+    torch.manual_seed(4321)                              # reproducible init and dropout seeds (rank 0's weights are broadcast)
+    model, crit, data, fwd_fl, desc, lr, wd, (H, dh, L) = build_workload(workload, B, S, a.dtype, device)
+    opt = FusedAdamW(model.parameters(), lr=lr, weight_decay=wd)
+    ddp = None
+    if world > 1 or force_dp:
+        from musicgeneration_amd.data_parallel import GradientBucketer
+        ddp = GradientBucketer(model, mode=a.dp_mode)
+    batches = [data.get() for _ in range(4)]          # resident in HBM before the timed region
+    model.train()
+
+    def step(i):
+        x, y = batches[i % len(batches)]
+        loss, _ = crit(model(x), y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if ddp is not None:
+            ddp.finish()
+        opt.step()
+        return loss
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    # HIP-event pairs around the MFMA kernels' launches, inside the timed region, on the first EVENT_STEPS steps
+    # only (~100 event pairs per step cost ~0.2 ms of the step they bracket)
+    EVENT_STEPS = min(3, steps)
+    events = ops.KERNEL_EVENTS = {}
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if i == EVENT_STEPS:
+            ops.KERNEL_EVENTS = None
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.KERNEL_EVENTS = None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss.detach())
+
+    tokens = world * B * S * steps
+    value = tokens / dt
+    train_fl = 3 * fwd_fl
+    # roofline: every MFMA kernel of the step is one of libmgx's and is timed by a HIP-event pair around its launches
+    # inside the timed region (musicgeneration_amd.ops._timed, on the stream the kernels run on); the headline
+    # `roofline` object is the one with the largest total time.  achieved = algorithmic FLOPs of the launches / their time.
+    labels = {"alibi_attn_fwd": "attn_fwd_mfma_kernel (ALiBi flash forward; QK^T + PV at half the square)",
+              "rel_attn_fwd": "rel_fwd_mfma_kernel (skew relative flash forward; QK^T + QE^T + PV at half the square)",
+              "rel_attn_bwd": "delta + rel_bwd_dkv + rel_bwd_dq (stores dG) + dE GEMM over the dG blocks + reduce (6 products "
+                              "at half the square; 12 executed: S, dP and Q.E^T are recomputed in the dK/dV and dQ kernels)",
+              "alibi_attn_bwd": "attn_bwd_stats_kernel + attn_bwd_dkv_pipe_kernel + attn_bwd_dq_pipe_kernel (5 products at half the square)",
+              "gemm_nt": "gemm_nt_kernel (every x.W and dy.W^T projection of the blocks and the head: forward + dgrad, "
+                         "bias / residual / activation-backward epilogues)",
+              "gemm_tn": "gemm_tn_kernel + splitk_reduce_kernel (weight gradients of the blocks, split-K fp32 slabs)",
+              "gemm_tn_head": "gemm_tn_kernel + splitk_reduce_kernel (head weight gradient)",
+              "gemm_tn_embed": "gemm_tn_kernel + splitk_reduce_kernel (embedding gradient as a one-hot GEMM)"}
+    lines = []
+    for name, ev in events.items():
+        if name not in labels or not ev:
+            continue
+        tot_ms = sum(s.elapsed_time(e) for s, e, _ in ev)
+        fl = sum(w for _, _, w in ev)
+        ach = fl / (tot_ms * 1e-3) / 1e12
+        traffic = None
+        if workload == "train_unified" and a.dtype == "bf16" and (B, S, H, dh) == (16, 2048, 8, 128):   # d=1024 ff=4096 fixed by the workload
+            traffic = pmc_traffic(name)
+        lines.append({"bound": "mfma", "kernel": labels[name], "achieved": ach, "peak": PEAK_BF16_TFLOPS,
+                      "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                      "traffic_unit": f"HBM bytes per launch (TCC FETCH_SIZE x2 + WRITE_SIZE, profiles/{TRAFFIC_FILE})",
+                      "launches_timed": len(ev), "avg_launch_ms": tot_ms / len(ev), "flops_per_launch": fl / len(ev),
+                      "ms_per_step": tot_ms / EVENT_STEPS})
+    lines.sort(key=lambda r: -r["ms_per_step"])
+    roof = lines[0] if lines else None
+    out = {
+        "metric": "training tokens/sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic MIDI-grammar tokens, random-init weights",
+        "config": {"workload": f"{workload}: {desc}, seq {S}, batch {B}/GPU, dropout 0.1, fused AdamW",
+                   "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
+        "step_tflops": value * train_fl / 1e12, "step_frac_of_bf16_peak": value * train_fl / 1e12 / PEAK_BF16_TFLOPS / world,
+        "final_loss": final_loss,
+        "roofline": roof,
+        "roofline_other_kernels": lines[1:],
+    }
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +258,8 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode half of the metric")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the train_separated / train_relative sub-records of the default run")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel path (RCCL group, gradient bucketer) with one rank: its test on a one-GPU box")
     ap.add_argument("--dp-mode", default="flat", choices=["flat", "inplace"], help="GradientBucketer exchange mode")
@@ -188,107 +292,21 @@ def main():
             dist.destroy_process_group()
         return
 
-    defaults = {"train_unified": (16, 2048), "train_separated": (8, 1024), "train_relative": (8, 4096)}[a.workload]
-    B = a.batch or defaults[0]
-    S = a.seq or defaults[1]
-    from musicgeneration_amd import ops
-    from musicgeneration_amd.optim import FusedAdamW
-    torch.manual_seed(4321)                              # reproducible init and dropout seeds (rank 0's weights are broadcast)
-    model, crit, data, fwd_fl, desc, lr, wd, (H, dh, L) = build_workload(a.workload, B, S, a.dtype, device)
-    opt = FusedAdamW(model.parameters(), lr=lr, weight_decay=wd)
-    ddp = None
-    if world > 1 or force_dp:
-        from musicgeneration_amd.data_parallel import GradientBucketer
-        ddp = GradientBucketer(model, mode=a.dp_mode)
-    batches = [data.get() for _ in range(4)]          # resident in HBM before the timed region
-    model.train()
-
-    def step(i):
-        x, y = batches[i % len(batches)]
-        loss, _ = crit(model(x), y)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        if ddp is not None:
-            ddp.finish()
-        opt.step()
-        return loss
-
-    for i in range(a.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # HIP-event pairs around the MFMA kernels' launches, inside the timed region, on the first EVENT_STEPS steps
-    # only (~100 event pairs per step cost ~0.2 ms of the step they bracket)
-    EVENT_STEPS = min(3, a.steps)
-    events = ops.KERNEL_EVENTS = {}
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        if i == EVENT_STEPS:
-            ops.KERNEL_EVENTS = None
-        loss = step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ops.KERNEL_EVENTS = None
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    final_loss = float(loss.detach())
-
-    tokens = world * B * S * a.steps
-    value = tokens / dt
-    train_fl = 3 * fwd_fl
-    # roofline: every MFMA kernel of the step is one of libmgx's and is timed by a HIP-event pair around its launches
-    # inside the timed region (musicgeneration_amd.ops._timed, on the stream the kernels run on); the headline
-    # `roofline` object is the one with the largest total time.  achieved = algorithmic FLOPs of the launches / their time.
-    labels = {"alibi_attn_fwd": "attn_fwd_mfma_kernel (ALiBi flash forward; QK^T + PV at half the square)",
-              "rel_attn_fwd": "rel_fwd_mfma_kernel (skew relative flash forward; QK^T + QE^T + PV at half the square)",
-              "rel_attn_bwd": "rel_bwd_dkv + rel_bwd_dq + rel_bwd_de + delta (6 products at half the square; 16 executed: "
-                              "S, dP and Q.E^T are recomputed in each of the three kernels)",
-              "alibi_attn_bwd": "attn_bwd_stats_kernel + attn_bwd_dkv_pipe_kernel + attn_bwd_dq_pipe_kernel (5 products at half the square)",
-              "gemm_nt": "gemm_nt_kernel (every x.W and dy.W^T projection of the blocks and the head: forward + dgrad, "
-                         "bias / residual / activation-backward epilogues)",
-              "gemm_tn": "gemm_tn_kernel + splitk_reduce_kernel (weight gradients of the blocks, split-K fp32 slabs)",
-              "gemm_tn_head": "gemm_tn_kernel + splitk_reduce_kernel (head weight gradient)",
-              "gemm_tn_embed": "gemm_tn_kernel + splitk_reduce_kernel (embedding gradient as a one-hot GEMM)"}
-    lines = []
-    for name, ev in events.items():
-        if name not in labels or not ev:
-            continue
-        tot_ms = sum(s.elapsed_time(e) for s, e, _ in ev)
-        fl = sum(w for _, _, w in ev)
-        ach = fl / (tot_ms * 1e-3) / 1e12
-        traffic = None
-        if a.workload == "train_unified" and a.dtype == "bf16" and (B, S, H, dh) == (16, 2048, 8, 128):   # d=1024 ff=4096 fixed by the workload
-            traffic = pmc_traffic(name)
-        lines.append({"bound": "mfma", "kernel": labels[name], "achieved": ach, "peak": PEAK_BF16_TFLOPS,
-                      "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
-                      "traffic_unit": f"HBM bytes per launch (TCC FETCH_SIZE x2 + WRITE_SIZE, profiles/{TRAFFIC_FILE})",
-                      "launches_timed": len(ev), "avg_launch_ms": tot_ms / len(ev), "flops_per_launch": fl / len(ev),
-                      "ms_per_step": tot_ms / EVENT_STEPS})
-    lines.sort(key=lambda r: -r["ms_per_step"])
-    roof = lines[0] if lines else None
-    out = {
-        "metric": "training tokens/sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic MIDI-grammar tokens, random-init weights",
-        "config": {"workload": f"{a.workload}: {desc}, seq {S}, batch {B}/GPU, dropout 0.1, fused AdamW",
-                   "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
-        "step_tflops": value * train_fl / 1e12, "step_frac_of_bf16_peak": value * train_fl / 1e12 / PEAK_BF16_TFLOPS / world,
-        "final_loss": final_loss,
-        "roofline": roof,
-        "roofline_other_kernels": lines[1:],
-    }
+    B = a.batch or DEFAULT_SHAPES[a.workload][0]
+    S = a.seq or DEFAULT_SHAPES[a.workload][1]
+    out = bench_training(a, a.workload, B, S, a.steps, a.warmup, device, rank, world, force_dp)
+    torch.cuda.empty_cache()
     if a.workload == "train_unified" and not a.no_decode:
         # the other half of BASELINE.json's metric, in the same driver-visible record
-        del model, opt, ddp, batches
-        torch.cuda.empty_cache()
         out["decode"] = bench_decode(a, device, rank, world, 64, 4096)
+    if a.workload == "train_unified" and not a.no_other_configs and a.batch is None and a.seq is None:
+        # BASELINE.json's other training configurations (configs[2] and configs[4]) in the same driver-visible record:
+        # fewer steps, same measurement
+        out["other_configs"] = {}
+        for wl in ("train_separated", "train_relative"):
+            torch.cuda.empty_cache()
+            out["other_configs"][wl] = bench_training(a, wl, *DEFAULT_SHAPES[wl], min(a.steps, 6), min(a.warmup, 2), device,
+                                                      rank, world, force_dp)
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
