@@ -16,6 +16,7 @@ tokens/s, fraction of the HBM roofline for the whole step and for the decode-att
 oracle's restatement of the reference step on the host cores (rank 0, N=1 only).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -175,6 +176,12 @@ def bench_training(a, workload, B, S, steps, warmup, device, rank, world, force_
 
     for i in range(warmup):
         step(i)
+    # The objects built so far (model, golden-size module trees, autograd graphs of the warm-up) leave the garbage
+    # collector's generations: a full collection over them takes ~90 ms on the host (tools/dp_probe.py: one such pause
+    # in the 7th step of a data-parallel run, whose bucket bookkeeping allocates the most containers per step), and
+    # early in a run the host is not yet far enough ahead of the GPU to hide it.
+    gc.collect()
+    gc.freeze()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -194,6 +201,7 @@ def bench_training(a, workload, B, S, steps, warmup, device, rank, world, force_
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ops.KERNEL_EVENTS = None
+    gc.unfreeze()
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -339,12 +347,15 @@ def bench_decode(a, device, rank, world, B, new):
     if world > 1:
         dist.barrier()
     seq0 = seq.clone()
+    gc.collect()
+    gc.freeze()                                                           # see bench_training
     t0 = time.perf_counter()
     sample_next_plus_one(model, seq, idx=64, deterministic=True)          # HIP-graph replay per step
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    gc.unfreeze()
     # second, untimed-for-`value` pass over the head of the same continuation, launch by launch, with a HIP-event
     # pair around every decode-attention launch (a graph replay cannot be bracketed per kernel)
     ev_new = min(new, 1024)

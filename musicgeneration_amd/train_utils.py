@@ -22,6 +22,7 @@ step does not stall the GPU:
 """
 from __future__ import annotations
 
+import gc
 import os
 import pathlib
 from typing import Optional
@@ -199,51 +200,59 @@ def training_loop(model, train_set, criterion, optimizer, lr_scheduler, logger, 
             save_checkpoint(_checkpoint_state(model, optimizer, scaler, criterion, lr_scheduler, steps), steps, run_dir)
             remove_extra_checkpoints(run_dir, keep=keep_checkpoints)
 
-    for _ in range(epochs):
-        for _i in tqdm(range(len(train_set))):
-            data = train_set.get()
-            x, y = recursive_cast(data, to_dev)
-            model.train()
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(mixed_precision)):
-                pred = model(x)
-                total_loss, loss_dict = criterion(pred, y)
-            optimizer.zero_grad(set_to_none=True)
-            total_loss.backward()
-            if ddp is not None:
-                ddp.finish()
-            optimizer.step()
+    # everything built so far (model, optimizer state, data pipeline) leaves the garbage collector's generations: a
+    # full collection over those objects is a ~0.1 s host pause that the GPU sees as an idle gap while the host is not
+    # yet far ahead of it (measured in the data-parallel bench: one 93 ms gap in the 7th step)
+    gc.collect()
+    gc.freeze()
+    try:
+        for _ in range(epochs):
+            for _i in tqdm(range(len(train_set))):
+                data = train_set.get()
+                x, y = recursive_cast(data, to_dev)
+                model.train()
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(mixed_precision)):
+                    pred = model(x)
+                    total_loss, loss_dict = criterion(pred, y)
+                optimizer.zero_grad(set_to_none=True)
+                total_loss.backward()
+                if ddp is not None:
+                    ddp.finish()
+                optimizer.step()
 
-            steps += batch_size
-            steps_since_log += batch_size
-            steps_since_checkpoint += batch_size
-            it += 1
-            pending.append((logger, recursive_cast(pred, lambda t: t.detach().argmax(-1)), y,
-                            recursive_cast(loss_dict, lambda t: t.detach())))
+                steps += batch_size
+                steps_since_log += batch_size
+                steps_since_checkpoint += batch_size
+                it += 1
+                pending.append((logger, recursive_cast(pred, lambda t: t.detach().argmax(-1)), y,
+                                recursive_cast(loss_dict, lambda t: t.detach())))
 
-            if eval_set is not None and eval_logger is not None and it % eval_every == 0:
-                with torch.no_grad():
-                    model.eval()
-                    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(mixed_precision)):
-                        ex, ey = recursive_cast(eval_set.get(), to_dev)
-                        epred = model(ex)
-                    pending.append((eval_logger, recursive_cast(epred, lambda t: t.argmax(-1)), ey, {}))
-            if len(pending) >= sync_every:
-                flush()
+                if eval_set is not None and eval_logger is not None and it % eval_every == 0:
+                    with torch.no_grad():
+                        model.eval()
+                        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(mixed_precision)):
+                            ex, ey = recursive_cast(eval_set.get(), to_dev)
+                            epred = model(ex)
+                        pending.append((eval_logger, recursive_cast(epred, lambda t: t.argmax(-1)), ey, {}))
+                if len(pending) >= sync_every:
+                    flush()
 
-            if steps_since_log // log_scalar_metric_step > 0:
-                flush()
-                logger.log.remote(steps, steps_since_log)
-                if eval_logger is not None:
-                    eval_logger.log.remote(steps, steps_since_log, prefix="eval")
-                steps_since_log = 0
+                if steps_since_log // log_scalar_metric_step > 0:
+                    flush()
+                    logger.log.remote(steps, steps_since_log)
+                    if eval_logger is not None:
+                        eval_logger.log.remote(steps, steps_since_log, prefix="eval")
+                    steps_since_log = 0
 
-            if steps_since_checkpoint // checkpoint_step > 0:
-                checkpoint()
-                steps_since_checkpoint = 0
-            if max_steps is not None and it >= max_steps:
-                flush()
-                return steps
-        flush()
-        lr_scheduler.step()
-        checkpoint()
+                if steps_since_checkpoint // checkpoint_step > 0:
+                    checkpoint()
+                    steps_since_checkpoint = 0
+                if max_steps is not None and it >= max_steps:
+                    flush()
+                    return steps
+            flush()
+            lr_scheduler.step()
+            checkpoint()
+    finally:
+        gc.unfreeze()
     return steps
