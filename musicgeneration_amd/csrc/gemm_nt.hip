@@ -95,8 +95,12 @@ __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 
         __builtin_amdgcn_sched_barrier(0);                     \
     } while (0)
 
-template <int EPI, int ACT, bool DROP>
+// HALF: the block tile is 128 x 256 (only the A0 half tile exists: the two quadrants of A1 are not computed, its
+// staging instructions keep their place in the schedule but all read one 16-byte piece).  For launches whose 256-row
+// tiles would leave a large part of the CUs idle (M = 8192 token rows against N = 1024: 128 tiles on 256 CUs).
+template <int EPI, int ACT, bool DROP, bool HALF>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
+    constexpr int BMT = HALF ? 128 : BM, NQA = HALF ? 1 : 2;
     __shared__ __attribute__((aligned(16))) char smem[2 * LDS_B];
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -106,13 +110,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
 
     // tile order: bands of 8 tile rows, column-major inside a band, so that the ~32 workgroups that share
     // an XCD at any time cover a compact 8 x 4 rectangle (12 operand panels per K tile for 32 tiles)
-    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM;
+    const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BMT - 1) / BMT;
     const int tile = xcd_remap(blockIdx.x, nbm * nbn);
     const int band = tile / (8 * nbn);
     const int bh = min(8, nbm - 8 * band);
     const int rem = tile - band * 8 * nbn;
     const int bn = rem / bh, bm = 8 * band + (rem - bn * bh);
-    const int m0 = bm * BM, n0 = bn * BN;
+    const int m0 = bm * BMT, n0 = bn * BN;
 
     // ---- staging: per-lane source byte offsets (32 bit), [half X][piece i]; piece 2w+i = rows 16w+8i.. of the half tile
     unsigned sa[2][2], sb[2][2];
@@ -123,6 +127,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
             const int row = 16 * w + 8 * i + (lane >> 3);
             const int ch = (lane & 7) ^ ((row >> 1) & 7);
             sa[X][i] = (unsigned)(((long)min(m0 + 128 * X + row, g.M - 1) * g.lda + ch * 8) * 2);
+            if (HALF && X == 1) sa[X][i] = (unsigned)((long)m0 * g.lda * 2);
             sb[X][i] = (unsigned)(((long)min(n0 + NT_COL0(row >> 5, X) + (row & 31), g.N - 1) * g.ldb + ch * 8) * 2);
         }
     const int nk = g.K / BK;
@@ -218,17 +223,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
         NT_MMA(0, 1, b1);
         NT_BAR();
         // phase 2: quadrant (A1, B1)
-        read_a(1, d);
+        if constexpr (!HALF) read_a(1, d);
         stage_a(0, d, t + 2);
         NT_BAR();
         NT_LGKM0();
-        NT_MMA(1, 1, b1);
+        if constexpr (!HALF) NT_MMA(1, 1, b1);
         NT_BAR();
         // phase 3: quadrant (A1, B0)
         stage_b(0, d, t + 2);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // A0, B0, B1 of K tile t+1 landed
         NT_BAR();
-        NT_MMA(1, 0, b0);
+        if constexpr (!HALF) NT_MMA(1, 0, b0);
         NT_BAR();
     };
     for (int t = 0; t < nk; t += 2) {
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-            for (int qa = 0; qa < 2; ++qa)
+            for (int qa = 0; qa < NQA; ++qa)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int nc = min(n0 + NT_COL0(wc, qb) + nsw, g.N - 8);
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-        for (int qa = 0; qa < 2; ++qa)
+        for (int qa = 0; qa < NQA; ++qa)
 #pragma unroll
             for (int i = 0; i < 4; ++i) block(qa, qb, i);
     if (EPI == EPI_DFAC && g.colpart) {
@@ -450,9 +455,24 @@ static int nt_check(const char* fn, const void* A, const void* Bt, const void* C
     return MGX_OK;
 }
 
+// 128-row tiles where 256-row tiles would fill at most three quarters of the chip's 256 CUs
+static inline bool nt_half_tiles(int M, int N) {
+    const long nblk = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    return nblk <= 192 && M > 128;
+}
+static inline long nt_blocks(int M, int N) {
+    const int bm = nt_half_tiles(M, N) ? 128 : BM;
+    return (long)((M + bm - 1) / bm) * ((N + BN - 1) / BN);
+}
 #define NT_LAUNCH(EPI, ACT, DROP)                                                                              \
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, ACT, DROP>), dim3((unsigned)nblk), dim3(NTHREADS), 0,              \
-                       (hipStream_t)stream, g)
+    do {                                                                                                       \
+        if (nt_half_tiles(M, N))                                                                               \
+            hipLaunchKernelGGL((gemm_nt_kernel<EPI, ACT, DROP, true>), dim3((unsigned)nblk), dim3(NTHREADS), 0, \
+                               (hipStream_t)stream, g);                                                        \
+        else                                                                                                   \
+            hipLaunchKernelGGL((gemm_nt_kernel<EPI, ACT, DROP, false>), dim3((unsigned)nblk), dim3(NTHREADS), 0, \
+                               (hipStream_t)stream, g);                                                        \
+    } while (0)
 
 extern "C" int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2, const float* bias, const void* res,
                                 int M, int N, int K, int lda, int ldb, int ldc, int act, float p_drop,
@@ -464,7 +484,7 @@ extern "C" int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2
     MGX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, MGX_EINVAL, "mgx_gemm_nt_bf16: p_drop=%f", p_drop);
     NtArgs g{(const char*)A, (const char*)Bt, (bf16_t*)C, (bf16_t*)C2, bias, (const bf16_t*)res, nullptr, nullptr,
              M, N, K, lda, ldb, ldc, p_drop, seed};
-    const long nblk = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const long nblk = nt_blocks(M, N);
     const bool drop = p_drop > 0.f;
     if (act < 0) NT_LAUNCH(EPI_PLAIN, 0, false);
     else if (act == MGX_ACT_GELU) { if (drop) NT_LAUNCH(EPI_ACT, MGX_ACT_GELU, true); else NT_LAUNCH(EPI_ACT, MGX_ACT_GELU, false); }
@@ -473,7 +493,7 @@ extern "C" int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2
     return MGX_OK;
 }
 
-extern "C" long mgx_gemm_nt_dfac_colpart_floats(int M, int N) { return (long)((M + BM - 1) / BM) * 2 * N; }
+extern "C" long mgx_gemm_nt_dfac_colpart_floats(int M, int N) { return (long)((M + 127) / 128) * 2 * N; }
 
 extern "C" int mgx_gemm_nt_dfac_bf16(const void* A, const void* Bt, const void* fac, void* C, float* colpart, float* dbias,
                                      int M, int N, int K, int lda, int ldb, int ldc, void* stream) {
@@ -482,11 +502,11 @@ extern "C" int mgx_gemm_nt_dfac_bf16(const void* A, const void* Bt, const void* 
     MGX_REQUIRE(!dbias || colpart, MGX_EINVAL, "mgx_gemm_nt_dfac_bf16: dbias needs the colpart workspace");
     NtArgs g{(const char*)A, (const char*)Bt, (bf16_t*)C, nullptr, nullptr, nullptr, (const bf16_t*)fac, colpart,
              M, N, K, lda, ldb, ldc, 0.f, 0ull};
-    const long nblk = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const long nblk = nt_blocks(M, N);
     NT_LAUNCH(EPI_DFAC, 0, false);
     MGX_CHECK_LAUNCH("gemm_nt_dfac");
     if (dbias) {
-        const int rows = 2 * ((M + BM - 1) / BM);
+        const int rows = 2 * (nt_half_tiles(M, N) ? (M + 127) / 128 : (M + BM - 1) / BM);
         hipLaunchKernelGGL(nt_colpart_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, (hipStream_t)stream, colpart,
                            dbias, rows, N);
         MGX_CHECK_LAUNCH("gemm_nt_dfac_reduce");
