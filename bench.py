@@ -241,6 +241,20 @@ def bench_training(a, workload, B, S, steps, warmup, device, rank, world, force_
                       "ms_per_step": tot_ms / EVENT_STEPS})
     lines.sort(key=lambda r: -r["ms_per_step"])
     roof = lines[0] if lines else None
+    # the HBM-bound kernels of the step, from the same event pairs: algorithmic bytes / time against the 8 TB/s peak
+    hbm_labels = {"ln_fwd": "ln_fwd_kernel ((dropout +) residual + LayerNorm forward)",
+                  "ln_bwd": "ln_bwd_kernel (LayerNorm backward + bias-gradient partials) + column_reduce_kernel",
+                  "adamw": "adamw_multi_kernel (28 B per parameter)"}
+    hbm_lines = []
+    for name, ev in events.items():
+        if name not in hbm_labels or not ev:
+            continue
+        tot_ms = sum(s.elapsed_time(e) for s, e, _ in ev)
+        by = sum(w for _, _, w in ev)
+        ach = by / (tot_ms * 1e-3) / 1e9
+        hbm_lines.append({"bound": "hbm", "kernel": hbm_labels[name], "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": ach / PEAK_HBM_GBS, "launches_timed": len(ev), "avg_launch_ms": tot_ms / len(ev),
+                          "bytes_per_launch": by / len(ev), "ms_per_step": tot_ms / EVENT_STEPS})
     out = {
         "metric": "training tokens/sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -251,6 +265,7 @@ def bench_training(a, workload, B, S, steps, warmup, device, rank, world, force_
         "final_loss": final_loss,
         "roofline": roof,
         "roofline_other_kernels": lines[1:],
+        "hbm_bound_kernels": hbm_lines,
     }
     return out
 

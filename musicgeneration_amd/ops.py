@@ -177,8 +177,10 @@ def ln_residual_fwd(a, res, gamma, beta, eps=1e-5, p_drop=0.0, seed=0, save=True
     z = torch.empty_like(a) if save else None
     mean = torch.empty(T, dtype=torch.float32, device=a.device) if save else None
     rstd = torch.empty(T, dtype=torch.float32, device=a.device) if save else None
-    check(lib.mgx_ln_residual_fwd(_p(a), _p(res), _p(gamma), _p(beta), _p(y), _p(z), _p(mean), _p(rstd), T, d, eps,
-                                  float(p_drop), seed, _dt(a), _stream()), "mgx_ln_residual_fwd")
+    # algorithmic bytes: a, res read; y, z written (bench.py's HBM lines)
+    with _timed("ln_fwd", float(a.numel() * a.element_size() * (2 + (res is not None) + bool(save)))):
+        check(lib.mgx_ln_residual_fwd(_p(a), _p(res), _p(gamma), _p(beta), _p(y), _p(z), _p(mean), _p(rstd), T, d, eps,
+                                      float(p_drop), seed, _dt(a), _stream()), "mgx_ln_residual_fwd")
     return y, z, mean, rstd
 
 
@@ -201,9 +203,11 @@ def ln_residual_bwd(dy, dy2, z, mean, rstd, gamma, p_drop=0.0, seed=0, want_dsum
     dbeta = torch.empty(d, dtype=torch.float32, device=z.device)
     dsum = torch.empty(d, dtype=torch.float32, device=z.device) if want_dsum else None
     partial = torch.empty(_PARTIAL_ROWS * 3 * d, dtype=torch.float32, device=z.device)
-    check(lib.mgx_ln_residual_bwd(_p(dy), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(da), _p(dgamma),
-                                  _p(dbeta), _p(dsum), _p(partial), T, d, float(p_drop), seed, _dt(z), _stream()),
-          "mgx_ln_residual_bwd")
+    # algorithmic bytes: dy, (dy2), z read; dz, (da) written
+    with _timed("ln_bwd", float(z.numel() * z.element_size() * (3 + (dy2 is not None) + (p_drop > 0)))):
+        check(lib.mgx_ln_residual_bwd(_p(dy), _p(dy2), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(da), _p(dgamma),
+                                      _p(dbeta), _p(dsum), _p(partial), T, d, float(p_drop), seed, _dt(z), _stream()),
+              "mgx_ln_residual_bwd")
     if want_dsum:
         return dz, da, dgamma, dbeta, dsum
     return dz, da, dgamma, dbeta
@@ -942,5 +946,6 @@ def adamw_step_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps
             raise ValueError("adamw_step_multi: size mismatch")
     arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
     sizes = (C.c_long * n)(*[p.numel() for p in params])
-    check(lib.mgx_adamw_multi(n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), sizes, lr, beta1, beta2, eps,
-                              weight_decay, step, grad_scale, _stream()), "mgx_adamw_multi")
+    with _timed("adamw", 28.0 * sum(p.numel() for p in params)):       # p, m, v read + written, g read: 28 B per parameter
+        check(lib.mgx_adamw_multi(n, arr(params), arr(grads), arr(exp_avgs), arr(exp_avg_sqs), sizes, lr, beta1, beta2, eps,
+                                  weight_decay, step, grad_scale, _stream()), "mgx_adamw_multi")
