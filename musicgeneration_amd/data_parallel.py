@@ -119,6 +119,9 @@ class GradientBucketer:
             flat = torch.zeros(off, dtype=dt, device=ps[0].device)
             self._flat.append(flat)
             self._views.append([flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, ps)])
+            # ops.grad_slot: the fused decoder block writes its weight gradients straight into these slots
+            for p, v in zip(ps, self._views[-1]):
+                p.mgx_grad_slot = v
 
     def _hook(self, p):
         b = self._bucket_of[id(p)]
@@ -128,7 +131,10 @@ class GradientBucketer:
 
     def _exchange(self, b):
         ps, flat = self.buckets[b], self._flat[b]
-        torch._foreach_copy_(self._views[b], [p.grad for p in ps])      # one multi-tensor launch
+        # gradients that were produced in place (ops.grad_slot) need no copy
+        todo = [(v, p.grad) for v, p in zip(self._views[b], ps) if p.grad.data_ptr() != v.data_ptr()]
+        if todo:
+            torch._foreach_copy_([v for v, _ in todo], [g for _, g in todo])      # one multi-tensor launch
         if self.avg:
             return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         flat.div_(self.world)

@@ -299,11 +299,12 @@ def gemm_nt_dfac(dy, bt, fac):
     return c, dbias
 
 
-def gemm_tn(a, b, out_dtype=torch.float32, tag="gemm_tn"):
+def gemm_tn(a, b, out_dtype=torch.float32, tag="gemm_tn", out=None):
     """C[M,N] = a[K,M]^T @ b[K,N] (weight gradient), fp32 accumulation over a split K.  b may be a column slice of a
     wider row-major matrix (row stride a multiple of 8).
     tag: name under which bench.py's HIP-event pairs file this launch (the block's four weight gradients are the
-    roofline population; the head and embedding gradients are filed apart)."""
+    roofline population; the head and embedding gradients are filed apart).
+    out: a contiguous [M,N] tensor to write into (a gradient-bucket slot, see grad_slot) instead of a fresh one."""
     _need(a, "a", torch.bfloat16)
     if not b.is_cuda or b.dtype != torch.bfloat16 or b.dim() != 2 or b.stride(1) != 1 or b.stride(0) % 8 or \
             b.stride(0) < b.shape[1] or b.storage_offset() % 8:
@@ -314,11 +315,27 @@ def gemm_tn(a, b, out_dtype=torch.float32, tag="gemm_tn"):
         raise ValueError(f"gemm_tn: a {tuple(a.shape)} b {tuple(b.shape)}: K must match, M and N multiples of 8")
     ws_n = lib.mgx_gemm_tn_workspace_floats(M, N, K, None)
     ws = torch.empty(ws_n, dtype=torch.float32, device=a.device)
-    c = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    if out is not None:
+        if out.shape != (M, N) or not out.is_contiguous() or not out.is_cuda or out.dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("gemm_tn: out must be a contiguous [M,N] fp32 / bf16 GPU tensor")
+        c = out
+    else:
+        c = torch.empty(M, N, dtype=out_dtype, device=a.device)
     with _timed(tag, 2.0 * M * N * K):
         check(lib.mgx_gemm_tn_bf16(_p(a), _p(b), _p(c), _p(ws), M, N, K, M, b.stride(0), _dt(c), _stream()),
               "mgx_gemm_tn_bf16")
     return c
+
+
+def grad_slot(master, shape):
+    """Where a weight gradient should be written: the parameter's slot of its data-parallel gradient bucket
+    (data_parallel.GradientBucketer tags every parameter with `mgx_grad_slot`), viewed as `shape`, when the parameter has
+    no gradient yet (autograd then adopts the returned tensor as p.grad, and the bucket needs no copy); None otherwise
+    (no bucketer, or a gradient is being accumulated: autograd would add the slot to itself)."""
+    slot = getattr(master, "mgx_grad_slot", None)
+    if slot is None or master.grad is not None or slot.dtype != torch.float32:
+        return None
+    return slot.view(shape)
 
 
 # ---------------------------------------------------------------------------
@@ -668,9 +685,9 @@ class _DecoderBlock(torch.autograd.Function):
         dh2 = dh2.reshape(T, d).contiguous()
         dz2, _, dg2, dbe2, db2 = ln_residual_bwd(dh2, None, z2, mean2, rstd2, W.m_g2, want_dsum=True)
         if mfma:
-            dw2 = gemm_tn(dz2, hact)                                                    # [d, ff]
+            dw2 = gemm_tn(dz2, hact, out=grad_slot(W.m_w2, (d, hact.shape[1])))         # [d, ff]
             dpre, db1 = gemm_nt_dfac(dz2, W.w2_t, pre)                                  # dz2 @ w2 through act' (+ db1)
-            dw1 = gemm_tn(dpre, h1)                                                     # [ff, d]
+            dw1 = gemm_tn(dpre, h1, out=grad_slot(W.m_w1, (dpre.shape[1], d)))          # [ff, d]
             dh1 = gemm_nt(dpre, W.w1_t)                                                 # [T, d]
         else:
             dw2 = torch.mm(dz2.t(), hact)
@@ -680,7 +697,7 @@ class _DecoderBlock(torch.autograd.Function):
         dz1, da1, dg1, dbe1, dbp = ln_residual_bwd(dh1, dz2, z1, mean1, rstd1, W.m_g1, p, seed1, want_dsum=True)
         a2 = a.view(T, d)
         if mfma:
-            dwp = gemm_tn(a2, da1)                                                      # [d, d]
+            dwp = gemm_tn(a2, da1, out=grad_slot(W.m_wp, (d, d)))                       # [d, d]
             da = gemm_nt(da1, W.wp).view(B, S, d)                                       # da1 @ wp^T
         else:
             dwp = torch.mm(a2.t(), da1)
@@ -695,7 +712,7 @@ class _DecoderBlock(torch.autograd.Function):
         dqkv2 = dqkv.view(T, 3 * d)
         dbqkv = colsum(dqkv2) if dqkv2.dtype == torch.bfloat16 and (3 * d) % 8 == 0 else dqkv2.sum(0, dtype=f32)
         if mfma:
-            dwqkv = gemm_tn(x2, dqkv2)                                                  # [d, 3d]
+            dwqkv = gemm_tn(x2, dqkv2, out=grad_slot(W.m_wqkv, (d, 3 * d)))             # [d, 3d]
             dx = gemm_nt(dqkv2, W.wqkv, None, dz1).view(B, S, d)                        # dqkv @ wqkv^T + dz1
         else:
             dwqkv = torch.mm(x2.t(), dqkv2)
