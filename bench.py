@@ -288,6 +288,18 @@ def main():
     ap.add_argument("--dp-mode", default="flat", choices=["flat", "inplace"], help="GradientBucketer exchange mode")
     a = ap.parse_args()
 
+    # stdout carries ONE line, the JSON record: anything libraries print on the way (RCCL writes its version banner to
+    # stdout when the communicator is created) goes to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(record):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(record), flush=True)
+        os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -310,7 +322,7 @@ def main():
     if a.workload == "decode_unified":
         out = bench_decode(a, device, rank, world, a.batch or 64, a.seq or 4096)
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            emit(out)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -333,7 +345,7 @@ def main():
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1 or force_dp:
         dist.destroy_process_group()
 
