@@ -221,7 +221,7 @@ def bench_training(a, workload, B, S, steps, warmup, device, rank, world, force_
               "alibi_attn_bwd": "attn_bwd_stats_kernel + attn_bwd_dkv_pipe_kernel + attn_bwd_dq_pipe_kernel (5 products at half the square)",
               "gemm_nt": "gemm_nt_kernel (every x.W and dy.W^T projection of the blocks and the head: forward + dgrad, "
                          "bias / residual / activation-backward epilogues)",
-              "gemm_tn": "gemm_tn_kernel + splitk_reduce_kernel (weight gradients of the blocks, split-K fp32 slabs)",
+              "gemm_tn": "gemm_tn_kernel + splitk_reduce_kernel (weight gradients of the blocks, two per launch, split-K fp32 slabs)",
               "gemm_tn_head": "gemm_tn_kernel + splitk_reduce_kernel (head weight gradient)",
               "gemm_tn_embed": "gemm_tn_kernel + splitk_reduce_kernel (embedding gradient as a one-hot GEMM)"}
     lines = []

@@ -269,6 +269,15 @@ int mgx_gemm_nt_dfac_bf16(const void* A, const void* Bt, const void* fac, void* 
 long mgx_gemm_tn_workspace_floats(int M, int N, int K, int* splits_out);
 int mgx_gemm_tn_bf16(const void* A, const void* B, void* C, float* workspace, int M, int N, int K,
                      int lda, int ldb, int out_dtype, void* stream);
+/* Two such weight gradients over the same K (token rows) in ONE launch: C0 = A0^T . B0 and C1 = A1^T . B1 (the
+ * gradients of linear1 and linear2, alibi_unified.py:90,92, or of c_attn and c_proj, :58,66).  Together the two have
+ * enough tiles for half as many K splits, i.e. half the fp32 slab traffic per gradient; results are bit-identical to
+ * two mgx_gemm_tn_bf16 calls only where the split count happens to be the same (the summation order over K differs
+ * otherwise; each order is fixed).  workspace: mgx_gemm_tn_pair_workspace_floats() floats. */
+long mgx_gemm_tn_pair_workspace_floats(int M0, int N0, int M1, int N1, int K);
+int mgx_gemm_tn_pair_bf16(const void* A0, const void* B0, void* C0, int M0, int N0, int lda0, int ldb0,
+                          const void* A1, const void* B1, void* C1, int M1, int N1, int lda1, int ldb1, int K,
+                          float* workspace, int out_dtype, void* stream);
 
 /* ---- decode-time projections (M <= 256 token rows) --------------------------------------------------
  * out[M,N] (bf16) = epilogue(A[M,K] . Wt[N,K]^T + bias[N]); A, Wt, res, out bf16 row-major; bias / gamma / beta fp32.

@@ -19,12 +19,18 @@ constexpr int BM = 256, BN = 256, BK = 64, NTHREADS = 512;
 constexpr int HT = 16384;
 constexpr int LDS_B = 65536;
 
-struct TnArgs {
+struct TnProb {
     const char* A;
     const char* B;
     float* C;                // fp32 slabs [splits][M, N]
-    int M, N, K;
+    int M, N;
     int lda, ldb;
+};
+struct TnArgs {
+    TnProb p[2];             // MODE 0: one or two problems share the launch (tiles of p[0] first); MODE 1: p[0]
+    int tiles0;              // tiles of p[0]; 0 tiles of p[1] when there is one problem
+    int tiles1;
+    int K;
     int ksplit_len;          // K elements per split (multiple of 64)
     // MODE 1 (dE of the skew relative attention from the dG blocks the dQ kernel stored, attn_rel_mfma.hip):
     // A = blocked dG, B = the packed qkv (q third of b = 0, h = 0), C = fp32 slabs [B*H][M][N]; M = padded number
@@ -104,14 +110,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs g) {
     // dimension fastest: the ~32 workgroups resident on one XCD cover a compact rectangle of tiles of ONE K split
     // and walk K together, so every A / B panel slice is fetched into that XCD's L2 once.
     int split = 0, m0, n0, kbeg, kend;
-    const char* Ab = g.A;
-    const char* Bb = g.B;
+    int sel = 0;
     if constexpr (MODE == 0) {
-        const int nbn = (g.N + BN - 1) / BN, nbm = (g.M + BM - 1) / BM;
-        const int ntile = nbm * nbn;
+        // two problems in one launch (the weight gradients of linear1 + linear2, of c_attn + c_proj): together they have
+        // enough tiles for half as many K splits, i.e. half the fp32 slab traffic per gradient
+        const int ntile = g.tiles0 + g.tiles1;
         const int wid = xcd_remap(blockIdx.x, gridDim.x);
         split = wid / ntile;
-        const int tile = wid - split * ntile;
+        int tile = wid - split * ntile;
+        sel = tile >= g.tiles0;
+        tile -= sel ? g.tiles0 : 0;
+        const int pM = sel ? g.p[1].M : g.p[0].M, pN = sel ? g.p[1].N : g.p[0].N;
+        const int nbn = (pN + BN - 1) / BN, nbm = (pM + BM - 1) / BM;
         int bm, bn;
         if (nbm <= nbn) {
             bn = tile / nbm;
@@ -124,7 +134,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs g) {
         n0 = bn * BN;
         kbeg = split * g.ksplit_len;
         kend = min(g.K, kbeg + g.ksplit_len);
-    } else {
+    }
+    const TnProb P = sel ? g.p[1] : g.p[0];
+    const char* Ab = P.A;
+    const char* Bb = P.B;
+    if constexpr (MODE == 1) {
         // dispatch order: every (b, h) of the tile row with the longest K range first; (b, h) % 8 = the XCD, the
         // same for all of its tiles (its q rows stay in that XCD's L2)
         const int ord = blockIdx.x / g.bk_bh, bh = blockIdx.x - ord * g.bk_bh;
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs g) {
         split = bh;
         const int b = bh / g.bk_h, h = bh - b * g.bk_h;
         Ab += ((long)bh * g.bk_nrb + (kbeg >> 5)) * g.bk_nrb * 2048;
-        Bb += ((long)b * g.K * g.ldb + (long)h * g.N) * 2;
+        Bb += ((long)b * g.K * P.ldb + (long)h * P.N) * 2;
     }
     const int nk = (kend - kbeg + BK - 1) / BK;
 
@@ -148,19 +162,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs g) {
         for (int i = 0; i < 2; ++i) {
             const int ch = 8 * i + 4 * (lane >> 5) + ((lane & 3) ^ ((srow >> 2) & 3));
             if constexpr (MODE == 0) {
-                sa[X][i] = (unsigned)(((long)srow * g.lda + min(m0 + 128 * X + ch * 8, g.M - 8)) * 2);
+                sa[X][i] = (unsigned)(((long)srow * P.lda + min(m0 + 128 * X + ch * 8, P.M - 8)) * 2);
             } else {
                 // query row srow of the K tile: unit srow >> 5, row srow & 31 of the block; 8 distances of block m >> 5
-                const int m = min(m0 + 128 * X + ch * 8, g.M - 8);
+                const int m = min(m0 + 128 * X + ch * 8, P.M - 8);
                 sa[X][i] = (unsigned)((((srow >> 5) * g.bk_nrb + (m >> 5)) * 2048) + ((m >> 4) & 1) * 1024 +
                                       (srow & 31) * 32 + (m & 15) * 2);
             }
-            sb[X][i] = (unsigned)(((long)srow * g.ldb + min(n0 + 128 * X + ch * 8, g.N - 8)) * 2);
+            sb[X][i] = (unsigned)(((long)srow * P.ldb + min(n0 + 128 * X + ch * 8, P.N - 8)) * 2);
         }
     char* const stage_base = smem + 2048 * w;
     auto stage_a = [&](int X, int d, int kt) {
         const int k0 = kbeg + min(kt, nk - 1) * BK;
-        const char* src = MODE == 0 ? Ab + (long)k0 * g.lda * 2 : Ab + (long)((k0 - kbeg) >> 5) * g.bk_nrb * 2048;
+        const char* src = MODE == 0 ? Ab + (long)k0 * P.lda * 2 : Ab + (long)((k0 - kbeg) >> 5) * g.bk_nrb * 2048;
         char* dst = stage_base + (2 * X + d) * HT;
         const char* p0 = src + sa[X][0];
         const char* p1 = src + sa[X][1];
@@ -170,7 +184,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs g) {
     };
     auto stage_b = [&](int X, int d, int kt) {
         const int k0 = kbeg + min(kt, nk - 1) * BK;
-        const char* src = Bb + (long)k0 * g.ldb * 2;
+        const char* src = Bb + (long)k0 * P.ldb * 2;
         char* dst = stage_base + LDS_B + (2 * X + d) * HT;
         const char* p0 = src + sb[X][0];
         const char* p1 = src + sb[X][1];
@@ -298,19 +312,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs g) {
 
     // fp32 slab store: D[row = n][col = m]: lane m = l15 holds 4 consecutive n per accumulator (16-byte stores,
     // 64 contiguous bytes per row and instruction)
-    float* C = g.C + (long)split * g.M * g.N;
+    float* C = P.C + (long)split * P.M * P.N;
 #pragma unroll
     for (int qa = 0; qa < 2; ++qa)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + 128 * qa + 64 * wr + 16 * i + l15;
-            if (m >= g.M) continue;
+            if (m >= P.M) continue;
 #pragma unroll
             for (int qb = 0; qb < (MODE == 0 ? 2 : 1); ++qb)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int n = n0 + 128 * qb + 32 * wc + 16 * j + 4 * g4;
-                    if (n + 4 <= g.N) *reinterpret_cast<f32x4*>(C + (long)m * g.N + n) = acc[qa][qb][i][j];
+                    if (n + 4 <= P.N) *reinterpret_cast<f32x4*>(C + (long)m * P.N + n) = acc[qa][qb][i][j];
                 }
         }
 }
@@ -332,49 +346,90 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" long mgx_gemm_tn_workspace_floats(int M, int N, int K, int* splits_out) {
-    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    // one workgroup per CU (128 KiB of LDS each) and equal work per workgroup: a single round of at
-    // most 256 workgroups has no tail and writes the fewest fp32 slabs
+static long tn_tiles(int M, int N) { return (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN); }
+// one workgroup per CU (128 KiB of LDS each) and equal work per workgroup: a single round of at most 256
+// workgroups has no tail and writes the fewest fp32 slabs
+static int tn_splits(long tiles, int K) {
     int splits = (int)(256 / tiles);
     const int max_splits = (K + 4 * BK - 1) / (4 * BK);     // at least 4 K tiles per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
+    const int len = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+    return (K + len - 1) / len;
+}
+static int tn_check(const char* fn, const void* A, const void* B, const void* C, int M, int N, int K, int lda, int ldb) {
+    MGX_REQUIRE(A && B && C, MGX_EINVAL, "%s: null pointer", fn);
+    MGX_REQUIRE(M >= 8 && N >= 8 && K > 0, MGX_EINVAL, "%s: M=%d N=%d K=%d", fn, M, N, K);
+    MGX_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N, MGX_EUNSUPPORTED,
+                "%s: M, N and leading dimensions must be multiples of 8: M=%d N=%d lda=%d ldb=%d", fn, M, N, lda, ldb);
+    MGX_REQUIRE(64L * lda < (1L << 31) && 64L * ldb < (1L << 31), MGX_EUNSUPPORTED, "%s: leading dimension too large", fn);
+    return MGX_OK;
+}
+static int tn_reduce(const float* slabs, void* C, long n, int splits, int out_dtype, hipStream_t st) {
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (out_dtype == MGX_F32)
+        hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, slabs, (float*)C, n, splits);
+    else
+        hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, slabs, (bf16_t*)C, n, splits);
+    MGX_CHECK_LAUNCH("splitk_reduce");
+    return MGX_OK;
+}
+
+extern "C" long mgx_gemm_tn_workspace_floats(int M, int N, int K, int* splits_out) {
+    const int splits = tn_splits(tn_tiles(M, N), K);
     if (splits_out) *splits_out = splits;
     return (long)splits * M * N;
 }
 
 extern "C" int mgx_gemm_tn_bf16(const void* A, const void* B, void* C, float* workspace, int M, int N, int K, int lda,
                                 int ldb, int out_dtype, void* stream) {
-    MGX_REQUIRE(A && B && C && workspace, MGX_EINVAL, "mgx_gemm_tn_bf16: null pointer");
-    MGX_REQUIRE(M >= 8 && N >= 8 && K > 0, MGX_EINVAL, "mgx_gemm_tn_bf16: M=%d N=%d K=%d", M, N, K);
-    MGX_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N, MGX_EUNSUPPORTED,
-                "mgx_gemm_tn_bf16: M, N and leading dimensions must be multiples of 8: M=%d N=%d lda=%d ldb=%d", M, N,
-                lda, ldb);
+    if (int rc = tn_check("mgx_gemm_tn_bf16", A, B, C, M, N, K, lda, ldb)) return rc;
+    MGX_REQUIRE(workspace, MGX_EINVAL, "mgx_gemm_tn_bf16: null workspace");
     MGX_REQUIRE(out_dtype == MGX_F32 || out_dtype == MGX_BF16, MGX_EINVAL, "mgx_gemm_tn_bf16: bad out dtype");
-    MGX_REQUIRE(64L * lda < (1L << 31) && 64L * ldb < (1L << 31), MGX_EUNSUPPORTED,
-                "mgx_gemm_tn_bf16: leading dimension too large");
-    int splits = 1;
-    mgx_gemm_tn_workspace_floats(M, N, K, &splits);
-    int len = ((K + splits - 1) / splits + BK - 1) / BK * BK;
-    splits = (K + len - 1) / len;
-    TnArgs g{(const char*)A, (const char*)B, workspace, M, N, K, lda, ldb, len, 0, 0, 0};
-    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const long tiles = tn_tiles(M, N);
+    const int splits = tn_splits(tiles, K);
+    const int len = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+    TnArgs g{{{(const char*)A, (const char*)B, workspace, M, N, lda, ldb}, {nullptr, nullptr, nullptr, 8, 8, 8, 8}},
+             (int)tiles, 0, K, len, 0, 0, 0};
     hipStream_t st = (hipStream_t)stream;
     if (K % BK == 0)
         hipLaunchKernelGGL((gemm_tn_kernel<false, 0>), dim3((unsigned)(tiles * splits)), dim3(NTHREADS), 0, st, g);
     else
         hipLaunchKernelGGL((gemm_tn_kernel<true, 0>), dim3((unsigned)(tiles * splits)), dim3(NTHREADS), 0, st, g);
     MGX_CHECK_LAUNCH("gemm_tn");
-    const long n = (long)M * N;
-    long blocks = (n / 4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    if (out_dtype == MGX_F32)
-        hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, workspace, (float*)C, n, splits);
+    return tn_reduce(workspace, C, (long)M * N, splits, out_dtype, st);
+}
+
+// Two weight gradients over the same K (token) dimension in one launch: together they have enough tiles for fewer K
+// splits (linear1 + linear2 of the block: 128 tiles x 2 splits instead of 64 x 4 each), i.e. half the slab traffic.
+extern "C" long mgx_gemm_tn_pair_workspace_floats(int M0, int N0, int M1, int N1, int K) {
+    return (long)tn_splits(tn_tiles(M0, N0) + tn_tiles(M1, N1), K) * ((long)M0 * N0 + (long)M1 * N1);
+}
+
+extern "C" int mgx_gemm_tn_pair_bf16(const void* A0, const void* B0, void* C0, int M0, int N0, int lda0, int ldb0,
+                                     const void* A1, const void* B1, void* C1, int M1, int N1, int lda1, int ldb1, int K,
+                                     float* workspace, int out_dtype, void* stream) {
+    if (int rc = tn_check("mgx_gemm_tn_pair_bf16", A0, B0, C0, M0, N0, K, lda0, ldb0)) return rc;
+    if (int rc = tn_check("mgx_gemm_tn_pair_bf16", A1, B1, C1, M1, N1, K, lda1, ldb1)) return rc;
+    MGX_REQUIRE(workspace, MGX_EINVAL, "mgx_gemm_tn_pair_bf16: null workspace");
+    MGX_REQUIRE(out_dtype == MGX_F32 || out_dtype == MGX_BF16, MGX_EINVAL, "mgx_gemm_tn_pair_bf16: bad out dtype");
+    const long t0 = tn_tiles(M0, N0), t1 = tn_tiles(M1, N1);
+    const int splits = tn_splits(t0 + t1, K);
+    const int len = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+    float* ws1 = workspace + (long)splits * M0 * N0;
+    TnArgs g{{{(const char*)A0, (const char*)B0, workspace, M0, N0, lda0, ldb0},
+              {(const char*)A1, (const char*)B1, ws1, M1, N1, lda1, ldb1}},
+             (int)t0, (int)t1, K, len, 0, 0, 0};
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((t0 + t1) * splits);
+    if (K % BK == 0)
+        hipLaunchKernelGGL((gemm_tn_kernel<false, 0>), dim3(grid), dim3(NTHREADS), 0, st, g);
     else
-        hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, workspace, (bf16_t*)C, n, splits);
-    MGX_CHECK_LAUNCH("splitk_reduce");
-    return MGX_OK;
+        hipLaunchKernelGGL((gemm_tn_kernel<true, 0>), dim3(grid), dim3(NTHREADS), 0, st, g);
+    MGX_CHECK_LAUNCH("gemm_tn_pair");
+    if (int rc = tn_reduce(workspace, C0, (long)M0 * N0, splits, out_dtype, st)) return rc;
+    return tn_reduce(ws1, C1, (long)M1 * N1, splits, out_dtype, st);
 }
 
 // skew relative attention backward, dEr slabs from the dG blocks of rel_bwd_dq_mfma_kernel (attn_rel_mfma.hip).
@@ -384,7 +439,8 @@ int mgx_rel_de_from_dg(const void* dg, const void* qkv, float* slabs, int B, int
     const int Mp = nrb * 32;
     const int rs = 3 * H * dh;
     MGX_REQUIRE(64L * rs < (1L << 30), MGX_EUNSUPPORTED, "rel dE from dG: row stride too large");
-    TnArgs g{(const char*)dg, (const char*)qkv, slabs, Mp, dh, S, 0, rs, 0, B * H, H, nrb};
+    TnArgs g{{{(const char*)dg, (const char*)qkv, slabs, Mp, dh, 0, rs}, {nullptr, nullptr, nullptr, 8, 8, 8, 8}},
+             0, 0, S, 0, B * H, H, nrb};
     const int nT = (min(Mp, (S + 31) / 32 * 32) + BM - 1) / BM;       // distance tiles that hold a distance <= S - 1
     const unsigned grid = (unsigned)(B * H * nT);
     if (S % BK == 0)

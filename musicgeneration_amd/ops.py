@@ -327,6 +327,36 @@ def gemm_tn(a, b, out_dtype=torch.float32, tag="gemm_tn", out=None):
     return c
 
 
+def _tn_operands(a, b, out, name):
+    _need(a, name + " a", torch.bfloat16)
+    if not b.is_cuda or b.dtype != torch.bfloat16 or b.dim() != 2 or b.stride(1) != 1 or b.stride(0) % 8 or \
+            b.stride(0) < b.shape[1] or b.storage_offset() % 8:
+        raise ValueError(f"{name}: b must be a bf16 GPU matrix with unit column stride and 16-byte aligned rows")
+    K, M = a.shape
+    K2, N = b.shape
+    if K != K2 or M % 8 or N % 8:
+        raise ValueError(f"{name}: a {tuple(a.shape)} b {tuple(b.shape)}: K must match, M and N multiples of 8")
+    if out is not None and (out.shape != (M, N) or not out.is_contiguous() or not out.is_cuda or out.dtype != torch.float32):
+        raise ValueError(f"{name}: out must be a contiguous [M,N] fp32 GPU tensor")
+    return K, M, N
+
+
+def gemm_tn_pair(a0, b0, a1, b1, out0=None, out1=None, tag="gemm_tn"):
+    """(a0^T @ b0, a1^T @ b1) in one launch (mgx_gemm_tn_pair_bf16): two weight gradients over the same token rows share
+    the K splits, which halves the fp32 slab traffic per gradient.  fp32 results; out0 / out1 as in gemm_tn."""
+    K, M0, N0 = _tn_operands(a0, b0, out0, "gemm_tn_pair[0]")
+    K1, M1, N1 = _tn_operands(a1, b1, out1, "gemm_tn_pair[1]")
+    if K != K1:
+        raise ValueError("gemm_tn_pair: the two problems must share K")
+    ws = torch.empty(int(lib.mgx_gemm_tn_pair_workspace_floats(M0, N0, M1, N1, K)), dtype=torch.float32, device=a0.device)
+    c0 = out0 if out0 is not None else torch.empty(M0, N0, dtype=torch.float32, device=a0.device)
+    c1 = out1 if out1 is not None else torch.empty(M1, N1, dtype=torch.float32, device=a0.device)
+    with _timed(tag, 2.0 * K * (M0 * N0 + M1 * N1)):
+        check(lib.mgx_gemm_tn_pair_bf16(_p(a0), _p(b0), _p(c0), M0, N0, M0, b0.stride(0), _p(a1), _p(b1), _p(c1), M1, N1, M1,
+                                        b1.stride(0), K, _p(ws), _lib.F32, _stream()), "mgx_gemm_tn_pair_bf16")
+    return c0, c1
+
+
 def grad_slot(master, shape):
     """Where a weight gradient should be written: the parameter's slot of its data-parallel gradient bucket
     (data_parallel.GradientBucketer tags every parameter with `mgx_grad_slot`), viewed as `shape`, when the parameter has
@@ -685,9 +715,10 @@ class _DecoderBlock(torch.autograd.Function):
         dh2 = dh2.reshape(T, d).contiguous()
         dz2, _, dg2, dbe2, db2 = ln_residual_bwd(dh2, None, z2, mean2, rstd2, W.m_g2, want_dsum=True)
         if mfma:
-            dw2 = gemm_tn(dz2, hact, out=grad_slot(W.m_w2, (d, hact.shape[1])))         # [d, ff]
             dpre, db1 = gemm_nt_dfac(dz2, W.w2_t, pre)                                  # dz2 @ w2 through act' (+ db1)
-            dw1 = gemm_tn(dpre, h1, out=grad_slot(W.m_w1, (dpre.shape[1], d)))          # [ff, d]
+            # the two weight gradients of the MLP in one launch: [d, ff] and [ff, d]
+            dw2, dw1 = gemm_tn_pair(dz2, hact, dpre, h1, grad_slot(W.m_w2, (d, hact.shape[1])),
+                                    grad_slot(W.m_w1, (dpre.shape[1], d)))
             dh1 = gemm_nt(dpre, W.w1_t)                                                 # [T, d]
         else:
             dw2 = torch.mm(dz2.t(), hact)
@@ -697,7 +728,6 @@ class _DecoderBlock(torch.autograd.Function):
         dz1, da1, dg1, dbe1, dbp = ln_residual_bwd(dh1, dz2, z1, mean1, rstd1, W.m_g1, p, seed1, want_dsum=True)
         a2 = a.view(T, d)
         if mfma:
-            dwp = gemm_tn(a2, da1, out=grad_slot(W.m_wp, (d, d)))                       # [d, d]
             da = gemm_nt(da1, W.wp).view(B, S, d)                                       # da1 @ wp^T
         else:
             dwp = torch.mm(a2.t(), da1)
@@ -712,7 +742,8 @@ class _DecoderBlock(torch.autograd.Function):
         dqkv2 = dqkv.view(T, 3 * d)
         dbqkv = colsum(dqkv2) if dqkv2.dtype == torch.bfloat16 and (3 * d) % 8 == 0 else dqkv2.sum(0, dtype=f32)
         if mfma:
-            dwqkv = gemm_tn(x2, dqkv2, out=grad_slot(W.m_wqkv, (d, 3 * d)))             # [d, 3d]
+            # the two weight gradients of the attention projections in one launch: [d, d] and [d, 3d]
+            dwp, dwqkv = gemm_tn_pair(a2, da1, x2, dqkv2, grad_slot(W.m_wp, (d, d)), grad_slot(W.m_wqkv, (d, 3 * d)))
             dx = gemm_nt(dqkv2, W.wqkv, None, dz1).view(B, S, d)                        # dqkv @ wqkv^T + dz1
         else:
             dwqkv = torch.mm(x2.t(), dqkv2)

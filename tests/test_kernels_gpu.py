@@ -589,6 +589,29 @@ def test_gemm_tn(K, M, N, out_dtype):
     assert gu.rel_err(out.float(), ref) < (1e-4 if out_dtype == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("K,M0,N0,M1,N1", [(8192, 1024, 4096, 4096, 1024), (8192, 1024, 1024, 1024, 3072), (1000, 264, 520, 64, 128),
+                                            (333, 64, 128, 264, 256)])
+def test_gemm_tn_pair(K, M0, N0, M1, N1):
+    """Two weight gradients over the same token rows in one launch (shared K splits) against fp32 matmuls on the
+    bf16-rounded operands and against the single-problem entry point; bitwise reproducible; writes into given outputs."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(K + M0 + N1)
+    a0 = torch.randn(K, M0, generator=g).bfloat16().cuda()
+    b0 = (torch.randn(K, N0, generator=g) / K ** 0.5).bfloat16().cuda()
+    a1 = torch.randn(K, M1, generator=g).bfloat16().cuda()
+    wide = (torch.randn(K, N1 + 64, generator=g) / K ** 0.5).bfloat16().cuda()
+    b1 = wide[:, 8:8 + N1]                                      # a column slice of a wider matrix (row stride != N)
+    out1 = torch.full((M1, N1), float("nan"), device="cuda")
+    c0, c1 = ops.gemm_tn_pair(a0, b0, a1, b1, None, out1)
+    assert c1.data_ptr() == out1.data_ptr()
+    assert gu.rel_err(c0, a0.float().t() @ b0.float()) < 1e-4
+    assert gu.rel_err(c1, a1.float().t() @ b1.float()) < 1e-4
+    assert gu.rel_err(c0, ops.gemm_tn(a0, b0)) < 1e-5
+    assert gu.rel_err(c1, ops.gemm_tn(a1, b1.contiguous())) < 1e-5
+    d0, d1 = ops.gemm_tn_pair(a0, b0, a1, b1)
+    assert torch.equal(c0, d0) and torch.equal(c1, d1)
+
+
 def test_gemm_tn_exact_integers():
     ops = _ops()
     g = torch.Generator().manual_seed(2)

@@ -17,6 +17,9 @@ int mgx_gemm_nt_dfac_bf16(const void*, const void*, const void*, void*, float*, 
 long mgx_gemm_nt_dfac_colpart_floats(int, int);
 long mgx_gemm_tn_workspace_floats(int, int, int, int*);
 int mgx_gemm_tn_bf16(const void*, const void*, void*, float*, int, int, int, int, int, int, void*);
+long mgx_gemm_tn_pair_workspace_floats(int, int, int, int, int);
+int mgx_gemm_tn_pair_bf16(const void*, const void*, void*, int, int, int, int, const void*, const void*, void*, int, int, int, int,
+                          int, float*, int, void*);
 const char* mgx_last_error_string(void);
 }
 
@@ -241,6 +244,45 @@ static void run_tn(int K, int M, int N, int rounds, int reps) {
     hipFree(A); hipFree(B); hipFree(C); hipFree(ws); hipFree(ref); hipFree(rows);
 }
 
+// two weight gradients: two launches against the paired launch
+static void run_tn_pair(int K, int M0, int N0, int M1, int N1, int rounds, int reps) {
+    bf16_t *A0, *B0, *A1, *B1;
+    float *C0, *C1, *ws0, *ws1, *wsp;
+    CK(hipMalloc(&A0, (size_t)M0 * K * 2)); CK(hipMalloc(&B0, (size_t)N0 * K * 2));
+    CK(hipMalloc(&A1, (size_t)M1 * K * 2)); CK(hipMalloc(&B1, (size_t)N1 * K * 2));
+    CK(hipMalloc(&C0, (size_t)M0 * N0 * 4)); CK(hipMalloc(&C1, (size_t)M1 * N1 * 4));
+    CK(hipMalloc(&ws0, (size_t)mgx_gemm_tn_workspace_floats(M0, N0, K, nullptr) * 4));
+    CK(hipMalloc(&ws1, (size_t)mgx_gemm_tn_workspace_floats(M1, N1, K, nullptr) * 4));
+    CK(hipMalloc(&wsp, (size_t)mgx_gemm_tn_pair_workspace_floats(M0, N0, M1, N1, K) * 4));
+    fill_kernel<<<1024, 256>>>(A0, (long)M0 * K, 3u); fill_kernel<<<1024, 256>>>(B0, (long)N0 * K, 4u);
+    fill_kernel<<<1024, 256>>>(A1, (long)M1 * K, 5u); fill_kernel<<<1024, 256>>>(B1, (long)N1 * K, 6u);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<double> t[2];
+    for (int r = 0; r < rounds + 1; ++r)
+        for (int v = 0; v < 2; ++v) {
+            CK(hipEventRecord(e0));
+            for (int k = 0; k < reps; ++k) {
+                if (v == 0) {
+                    mgx_gemm_tn_bf16(A0, B0, C0, ws0, M0, N0, K, M0, N0, 0, nullptr);
+                    mgx_gemm_tn_bf16(A1, B1, C1, ws1, M1, N1, K, M1, N1, 0, nullptr);
+                } else {
+                    mgx_gemm_tn_pair_bf16(A0, B0, C0, M0, N0, M0, N0, A1, B1, C1, M1, N1, M1, N1, K, wsp, 0, nullptr);
+                }
+            }
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0) t[v].push_back(ms / reps);
+        }
+    const double fl = 2.0 * K * ((double)M0 * N0 + (double)M1 * N1);
+    printf("  TN pair K=%d [%dx%d]+[%dx%d]: two launches %.1f us = %.0f TF/s, paired %.1f us = %.0f TF/s\n", K, M0, N0, M1, N1,
+           median(t[0]) * 1e3, fl / median(t[0]) / 1e9, median(t[1]) * 1e3, fl / median(t[1]) / 1e9);
+    fflush(stdout);
+    hipFree(A0); hipFree(B0); hipFree(A1); hipFree(B1); hipFree(C0); hipFree(C1); hipFree(ws0); hipFree(ws1); hipFree(wsp);
+}
+
 static void run_mfma() {
     bf16_t* src;
     float* out;
@@ -286,6 +328,13 @@ int main(int argc, char** argv) {
         for (auto& s : shapes) run_tn(s[0], s[1], s[2], rounds, reps);
         return 0;
     }
-    fprintf(stderr, "usage: gemm_lab nt|tn|mfma [dims]\n");
+    if (mode == "tnpair") {
+        run_tn_pair(32768, 1024, 4096, 4096, 1024, rounds, reps);
+        run_tn_pair(32768, 1024, 1024, 1024, 3072, rounds, reps);
+        run_tn_pair(8192, 1024, 4096, 4096, 1024, rounds, reps);
+        run_tn_pair(8192, 1024, 1024, 1024, 3072, rounds, reps);
+        return 0;
+    }
+    fprintf(stderr, "usage: gemm_lab nt|tn|tnpair|mfma [dims]\n");
     return 1;
 }

@@ -19,12 +19,12 @@ fwd = nt(T, 3 * d, d) + nt(T, d, d, 1) + nt(T, ff, d, 1) + nt(T, d, ff, 1)      
 bwd = nt(T, ff, d, 1) + nt(T, d, ff) + nt(T, d, d) + nt(T, d, 3 * d)      # first one: dgrad x derivative factor (reads fac)
 nt_algo = (L * (fwd + bwd) + nt(T, Vp, d) + nt(T, d, Vp)) / (8 * L + 2)
 tn = lambda m, n: 2 * T * (m + n) + 4 * m * n                               # bf16 in, fp32 dW out
-tn_algo = (L * (tn(d, ff) + tn(ff, d) + tn(d, d) + tn(d, 3 * d)) + tn(d, Vp) + tn(Vp, d)) / (4 * L + 2)
+tn_algo = (L * (tn(d, ff) + tn(ff, d) + tn(d, d) + tn(d, 3 * d)) + tn(d, Vp) + tn(Vp, d)) / (2 * L + 2)   # the block's four gradients leave as two paired launches
 out = {}
 for key, name, tagf, tagw, pat, algo, also in (
         ("gemm_nt", "gemm_nt_kernel, the step's 50 launches (24 forward, 24 dgrad, head forward + dgrad)", "step_fetch",
          "step_write", "gemm_nt_kernel", nt_algo, None),
-        ("gemm_tn", "gemm_tn_kernel + splitk_reduce, the step's 26 launches (24 block weight gradients, head, embedding)",
+        ("gemm_tn", "gemm_tn_kernel + splitk_reduce, the step's 14 launches (12 paired block weight gradients, head, embedding)",
          "step_fetch", "step_write", "gemm_tn_kernel", tn_algo, ("splitk_reduce",)),
         ("alibi_attn_fwd", "attn_fwd_mfma_kernel<128,8> B16 S2048 H8", "step_fetch", "step_write", "attn_fwd_mfma_kernel",
          16 * 2048 * 3072 * 2 + 16 * 2048 * 1024 * 2 + 16 * 8 * 2048 * 4, None),
