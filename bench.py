@@ -30,7 +30,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0         # HBM3E spec, same table
-TRAFFIC_FILE = "r02c_traffic_pmc.json"
+TRAFFIC_FILE = "r02d_traffic_pmc.json"
 
 
 def pmc_traffic(key):

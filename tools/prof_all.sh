@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 for wl in train_unified train_separated train_relative decode_unified; do
   extra="--steps 6 --warmup 3"
   [ $wl = decode_unified ] && extra="--seq 512"
-  [ $wl = train_unified ] && extra="$extra --no-decode"
+  [ $wl = train_unified ] && extra="$extra --no-decode --no-other-configs"
   bash $R/tools/prof.sh ${tag}_$wl --workload $wl $extra > $R/gpurun_out/${tag}_${wl}_bench_line.json || { tail -20 $R/gpurun_out/prof_${tag}_$wl.log; exit 1; }
   python3 $R/tools/profsum.py $R/gpurun_out/prof_${tag}_$wl > $R/gpurun_out/${tag}_${wl}_summary.txt
   cp $(ls $R/gpurun_out/prof_${tag}_$wl/*/*kernel_stats.csv | tail -1) $R/gpurun_out/${tag}_${wl}_kernel_stats.csv

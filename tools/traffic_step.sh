@@ -11,7 +11,7 @@ run() {  # tag counter script args...
   timeout -s KILL 240 rocprofv3 --pmc $ctr --output-format csv -d $R/gpurun_out/tr2_$tag -- python3 "$@" > $R/gpurun_out/tr2_$tag.log 2>&1 || { tail -5 $R/gpurun_out/tr2_$tag.log; exit 1; }
   echo "pass $tag done"
 }
-STEP="$R/bench.py --workload train_unified --steps 1 --warmup 1 --no-decode --no-cpu-baseline"
+STEP="$R/bench.py --workload train_unified --steps 1 --warmup 1 --no-decode --no-other-configs --no-cpu-baseline"
 run step_fetch FETCH_SIZE $STEP && \
 run step_write WRITE_SIZE $STEP && \
 run dec_fetch FETCH_SIZE $R/tools/decode_one.py 2112 5 && \
