@@ -397,7 +397,9 @@ __global__ __launch_bounds__(64 * NW, 2) void rel_bwd_dq_mfma_kernel(
                         const float v = row[(r - l31 - 1) & 63];
                         dgf[e] = (bf16_t)((r > qi) ? 0.f : v);     // r > i: key index below 0, never written
                     }
-                    *reinterpret_cast<bf16x8*>(dgp + ((long)(R0 >> 5) << 11) + 1024 * s2) = dgf;
+                    // written once, read once by the dE GEMM: non-temporal, so that the 1.07 GB do not push the K / V tiles
+                    // out of L2 (relative backward 1.61 -> 1.55 ms per layer at B8 S4096)
+                    __builtin_nontemporal_store(dgf, reinterpret_cast<bf16x8*>(dgp + ((long)(R0 >> 5) << 11) + 1024 * s2));
 #pragma unroll
                     for (int d = 0; d < DH / 32; ++d)
                         dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(etf[s2][d], dgf, dq[d], 0, 0, 0);

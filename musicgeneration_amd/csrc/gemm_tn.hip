@@ -179,6 +179,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs g) {
         const char* p0 = src + sa[X][0];
         const char* p1 = src + sa[X][1];
         if (TAIL && k0 + srow >= kend) p0 = p1 = (const char*)g_tn_zero16;
+        if constexpr (MODE == 1) {
+            // the dG blocks are read exactly once: non-temporal (aux = 2), the q rows keep the L2 to themselves
+            __builtin_amdgcn_global_load_lds((const void*)p0, (lds_void*)(dst), 16, 0, 2);
+            __builtin_amdgcn_global_load_lds((const void*)p1, (lds_void*)(dst + 1024), 16, 0, 2);
+            return;
+        }
         __builtin_amdgcn_global_load_lds((const void*)p0, (lds_void*)(dst), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const void*)p1, (lds_void*)(dst + 1024), 16, 0, 0);
     };
