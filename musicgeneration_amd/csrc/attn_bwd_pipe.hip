@@ -528,7 +528,12 @@ int mgx_attn_bwd_dkv_pipe(const void* dout, const void* qkv, const void* out, co
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MGX_ELAUNCH;
         n_cu = prop.multiProcessorCount;
     }
-    const int grid = a.nwork < n_cu ? a.nwork : n_cu;     // one persistent workgroup per CU
+    // Persistent workgroups, one resident per CU (registers), TWO per CU in the grid: the second half is handed out by
+    // the dispatcher as CUs come free.  On an idle chip that costs nothing measurable (639 against 641 us per backward);
+    // when another kernel holds some CUs -- RCCL's reduction kernels during the data-parallel backward -- the work
+    // lists are half as long, so the workgroups that had to wait add half as much.
+    constexpr int kGridPerCu = 2;
+    const int grid = a.nwork < n_cu * kGridPerCu ? a.nwork : n_cu * kGridPerCu;
     if (dh == 64) {
         hipLaunchKernelGGL((attn_bwd_stats_kernel<64>), gs, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
                            lse, slopes, nla, nda, nd32, n_chunks, S, Sp, H, 1.f / c);

@@ -1,6 +1,6 @@
 """How much does a resident foreign kernel (k CUs held for T us from the start of every backward, on a side stream)
 cost the training step?  A one-GPU stand-in for RCCL's reduction kernels in an N > 1 run.
-usage: python tools/cu_hog_probe.py  (needs tools/lab/libcu_hog.so, see tools/lab/cu_hog.hip)"""
+usage: python tools/cu_hog_probe.py [short]  (needs tools/lab/libcu_hog.so, see tools/lab/cu_hog.hip)"""
 import sys, os, time, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -46,7 +46,8 @@ run(0, 0, 4, 2)
 gc.collect(); gc.freeze()
 base = run(0, 0)
 print(f"no hog: {base:.2f} ms/step", flush=True)
-for k in (8, 16, 32, 64):
+short = len(sys.argv) > 1 and sys.argv[1] == "short"
+for k in ((16,) if short else (8, 16, 32, 64)):
     for usec in (2000, 4000):
         t = run(k, usec)
         print(f"hog {k:3d} CUs x {usec} us: {t:.2f} ms/step (+{t - base:.2f})", flush=True)
