@@ -66,10 +66,11 @@ def test_alibi_attention_fp32(B, S, H, dh):
     assert gu.rel_err(lse, torch.logsumexp(s, -1)) < F32_TOL
 
 
-# the last two: more (batch, head, key-block) pairs than CUs, so that the persistent dK/dV workgroups walk several
-# items each (an odd number of key blocks leaves the middle one unpaired) and the tile stream crosses item boundaries
+# the last three: more (batch, head, key-block) pairs than workgroups in the persistent grid (2 per CU = 512), so that
+# the dK/dV and dQ workgroups walk several pairs each (576 pairs: one or two; 1120: two or three; an odd number of key
+# blocks leaves the middle one unpaired) and the tile stream crosses item boundaries; 480 pairs: one pair per workgroup
 @pytest.mark.parametrize("B,S,H,dh", [(2, 130, 4, 64), (1, 257, 2, 128), (2, 384, 2, 64), (1, 512, 8, 128),
-                                       (1, 100, 2, 16), (6, 300, 48, 64), (5, 520, 32, 128)])
+                                       (1, 100, 2, 16), (6, 300, 48, 64), (5, 520, 32, 128), (7, 300, 80, 64)])
 @pytest.mark.parametrize("force_generic", [False, True])
 def test_alibi_attention_bf16(B, S, H, dh, force_generic):
     ops = _ops()
