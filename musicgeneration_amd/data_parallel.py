@@ -28,6 +28,7 @@ over ranks of the per-rank losses (and gradients) equals the single-process loss
 """
 from __future__ import annotations
 
+import contextlib
 from typing import List
 
 import torch
@@ -91,17 +92,62 @@ class GradientBucketer:
         self._bucket_of = {id(p): b for b, ps in enumerate(self.buckets) for p in ps}
         self._pending = [len(b) for b in self.buckets]
         self._work = []
-        for p in params:
-            p.register_post_accumulate_grad_hook(self._hook)
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in params]
         # identical replicas: broadcast rank 0's weights once
         for p in model.parameters():
             dist.broadcast(p.data, src=0, group=process_group)
             torch.autograd.graph.increment_version(p)    # written through .data: version-keyed weight shadows must refresh
         for b in model.buffers():
             dist.broadcast(b.data, src=0, group=process_group)
+        # The global CE normaliser is a blocking all-reduce issued from the criterion's forward: EVERY rank must
+        # evaluate the criterion the same number of times with gradients enabled.  Evaluations under torch.no_grad()
+        # (a validation loss on one rank) keep the local normaliser and exchange nothing.  close() (or leaving the
+        # `with` block) restores whatever hook was installed before, so a later model / process group in the same
+        # process does not inherit this one's group.
+        self._hooked = False
         if global_loss_normaliser and self.world > 1:
             from . import ops
-            ops.LOSS_DENOMINATOR_HOOK = lambda den: global_mean_denominator(den, process_group)
+            self._prev_hook = ops.LOSS_DENOMINATOR_HOOK
+            self._own_hook = self._denominator
+            ops.LOSS_DENOMINATOR_HOOK = self._own_hook
+            self._hooked = True
+
+    def _denominator(self, den):
+        return global_mean_denominator(den, self.group)
+
+    def close(self):
+        """Detach from the model's process-wide state: the CE denominator hook goes back to what it was, the
+        gradient hooks and the bucket-slot tags of the parameters are removed.  Idempotent."""
+        if self._hooked:
+            from . import ops
+            if ops.LOSS_DENOMINATOR_HOOK is self._own_hook:
+                ops.LOSS_DENOMINATOR_HOOK = self._prev_hook
+            self._hooked = False
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+        for p in self.params:
+            for tag in ("mgx_grad_slot", "mgx_slot_claimed"):
+                if hasattr(p, tag):
+                    delattr(p, tag)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    @contextlib.contextmanager
+    def local_loss_normaliser(self):
+        """Criterion evaluations inside the block use the rank-local normaliser and exchange nothing (a reference
+        loss on one rank, a side model)."""
+        from . import ops
+        saved, ops.LOSS_DENOMINATOR_HOOK = ops.LOSS_DENOMINATOR_HOOK, None
+        try:
+            yield
+        finally:
+            ops.LOSS_DENOMINATOR_HOOK = saved
 
     def _alloc_flat(self):
         # one persistent flat buffer per bucket, every parameter's slot 16-byte aligned; after the exchange
@@ -124,6 +170,7 @@ class GradientBucketer:
                 p.mgx_grad_slot = v
 
     def _hook(self, p):
+        p.mgx_slot_claimed = False                       # ops.grad_slot: the slot may be handed out again next backward
         b = self._bucket_of[id(p)]
         self._pending[b] -= 1
         if self._pending[b] == 0:

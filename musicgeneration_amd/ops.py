@@ -361,10 +361,14 @@ def grad_slot(master, shape):
     """Where a weight gradient should be written: the parameter's slot of its data-parallel gradient bucket
     (data_parallel.GradientBucketer tags every parameter with `mgx_grad_slot`), viewed as `shape`, when the parameter has
     no gradient yet (autograd then adopts the returned tensor as p.grad, and the bucket needs no copy); None otherwise
-    (no bucketer, or a gradient is being accumulated: autograd would add the slot to itself)."""
+    (no bucketer, or a gradient is being accumulated: autograd would add the slot to itself).  A slot is handed out
+    at most once per backward: a parameter that feeds two producer nodes of one graph (shared weights, a block applied
+    twice) gets it for the first and None for the others, whose gradients autograd then adds; the bucketer's
+    post-accumulate hook releases the claim."""
     slot = getattr(master, "mgx_grad_slot", None)
-    if slot is None or master.grad is not None or slot.dtype != torch.float32:
+    if slot is None or master.grad is not None or slot.dtype != torch.float32 or getattr(master, "mgx_slot_claimed", False):
         return None
+    master.mgx_slot_claimed = True
     return slot.view(shape)
 
 
@@ -381,7 +385,7 @@ LOSS_DENOMINATOR_HOOK = None
 
 class _SoftmaxXent(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, targets, weight, ignore_index, col0, V):
+    def forward(ctx, logits, targets, weight, ignore_index, col0, V, den_hook):
         _need(logits, "logits")
         ld = logits.shape[-1]
         T = logits.numel() // ld
@@ -403,8 +407,8 @@ class _SoftmaxXent(torch.autograd.Function):
         ii = -100 if ignore_index is None else int(ignore_index)
         check(lib.mgx_softmax_xent_fwd(_p(logits), _p(tgt), _p(weight), _p(row_loss), _p(row_lse), _p(sums), T, V, ld,
                                        col0, ii, _dt(logits), _stream()), "mgx_softmax_xent_fwd")
-        if LOSS_DENOMINATOR_HOOK is not None:
-            sums[1:2].copy_(LOSS_DENOMINATOR_HOOK(sums[1:2]))      # the backward kernel divides by sums[1] too
+        if den_hook is not None:
+            sums[1:2].copy_(den_hook(sums[1:2]))                   # the backward kernel divides by sums[1] too
         ctx.save_for_backward(logits, tgt, weight, row_lse, sums)
         ctx.meta = (T, V, ld, col0, ii)
         return sums[0] / sums[1]
@@ -424,13 +428,20 @@ class _SoftmaxXent(torch.autograd.Function):
             dlogits = torch.zeros_like(logits)
         check(lib.mgx_softmax_xent_bwd(_p(logits), _p(tgt), _p(weight), _p(row_lse), _p(sums), _p(g), _p(dlogits), T, V,
                                        ld, col0, ii, _dt(logits), _stream()), "mgx_softmax_xent_bwd")
-        return dlogits, None, None, None, None, None
+        return dlogits, None, None, None, None, None, None
+
+
+def _denominator_hook():
+    # Read outside the autograd node (grad mode is always off inside Function.forward).  Evaluations under
+    # torch.no_grad() - a validation loss, possibly on one rank only - keep the rank-local normaliser and exchange
+    # nothing; with gradients enabled every rank must evaluate the criterion the same number of times.
+    return LOSS_DENOMINATOR_HOOK if torch.is_grad_enabled() else None
 
 
 def softmax_cross_entropy(logits, targets, weight=None, ignore_index=None, col0=0, V=None):
     """Mean (weighted) CE of logits[..., col0:col0+V] against targets; fp32 scalar."""
     V = logits.shape[-1] - col0 if V is None else V
-    return _SoftmaxXent.apply(logits, targets, weight, ignore_index, col0, V)
+    return _SoftmaxXent.apply(logits, targets, weight, ignore_index, col0, V, _denominator_hook())
 
 
 class _SoftmaxXentMulti(torch.autograd.Function):
@@ -439,7 +450,7 @@ class _SoftmaxXentMulti(torch.autograd.Function):
     kernel fills in its own column range (three zero-filled [T, ld] buffers and their sum otherwise)."""
 
     @staticmethod
-    def forward(ctx, logits, specs, *tensors):
+    def forward(ctx, logits, specs, den_hook, *tensors):
         # specs: tuple of (ignore_index, col0, V); tensors: (targets_k, weight_k or None) per head
         _need(logits, "logits")
         ld = logits.shape[-1]
@@ -466,8 +477,8 @@ class _SoftmaxXentMulti(torch.autograd.Function):
                                            col0, iik, _dt(logits), _stream()), "mgx_softmax_xent_fwd")
             saved += [tgt, weight, row_lse, sums]
         all_sums = saved[3::4]
-        if LOSS_DENOMINATOR_HOOK is not None:                       # one exchange for every head's denominator
-            den = LOSS_DENOMINATOR_HOOK(torch.stack([t[1] for t in all_sums]))
+        if den_hook is not None:                                    # one exchange for every head's denominator
+            den = den_hook(torch.stack([t[1] for t in all_sums]))
             for k, t in enumerate(all_sums):
                 t[1:2].copy_(den[k:k + 1])
         losses = [t[0] / t[1] for t in all_sums]
@@ -494,7 +505,7 @@ class _SoftmaxXentMulti(torch.autograd.Function):
             iik = -100 if ii is None else int(ii)
             check(lib.mgx_softmax_xent_bwd(_p(logits), _p(tgt), _p(weight), _p(row_lse), _p(sums), _p(g), _p(dlogits), T, V,
                                            ld, col0, iik, _dt(logits), _stream()), "mgx_softmax_xent_bwd")
-        return (dlogits, None) + (None,) * (2 * len(ctx.specs))
+        return (dlogits, None, None) + (None,) * (2 * len(ctx.specs))
 
 
 def softmax_cross_entropy_multi(logits, heads):
@@ -503,7 +514,7 @@ def softmax_cross_entropy_multi(logits, heads):
     tensors = []
     for tgt, w, _, _, _ in heads:
         tensors += [tgt, w]
-    return _SoftmaxXentMulti.apply(logits, specs, *tensors)
+    return _SoftmaxXentMulti.apply(logits, specs, _denominator_hook(), *tensors)
 
 
 # ---------------------------------------------------------------------------

@@ -141,6 +141,13 @@ dist.all_reduce(mine)
 nums, dens = num.clone(), den.clone()
 dist.all_reduce(nums); dist.all_reduce(dens)
 assert torch.allclose(mine / world, nums / dens), (mine / world, nums / dens)
+# close() hands the process-wide hook back and removes the gradient hooks and slot tags
+ddp.close()
+assert ops.LOSS_DENOMINATOR_HOOK is None
+assert not any(hasattr(p, "mgx_grad_slot") for p in model.parameters())
+model.zero_grad()
+((model(xs) - ys) ** 2).mean().backward()          # no exchange any more: would raise / hang if a hook were left
+ddp.close()                                        # idempotent
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
