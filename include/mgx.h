@@ -17,7 +17,9 @@
  *     statistics (lse, mean, rstd, losses) are always fp32
  *   - return value: 0 on success, a negative MGX_E* code otherwise (never throws);
  *     mgx_last_error_string() describes the last failure on the calling thread
- *   - re-entrant and thread-safe: no mutable global state
+ *   - re-entrant and thread-safe.  The library's only state beyond the per-thread error string: a per-device cache
+ *     of the compute-unit count (immutable once looked up) and, for mgx_colsum_bf16_static alone, that entry's
+ *     device-resident scratch array with its per-device address table (see its comment: overlapping calls race)
  *   - tensors are dense row-major with the shapes given per function
  */
 #ifndef MGX_H
@@ -256,10 +258,13 @@ int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2, const flo
 /* NT with the backward of `drop(activation(.))` (alibi_unified.py:90-91) as its epilogue: the dgrad GEMM of
  * linear2 (autograd of alibi_unified.py:92) times the derivative factor the forward left, in one launch:
  *   C[M,N] = (A[M,K] . Bt[N,K]^T) * fac[M,N]      fac [M,N] bf16 (ld = ldc) = C of mgx_gemm_nt_bf16 with act >= 0;
- *   colpart [mgx_gemm_nt_dfac_colpart_floats(M,N)] fp32 (may be NULL) = [2*ceil(M/256), N] partial column sums of
- *   the rounded C, one row per 128-row slab (plus one for the second wave row of each tile): their sum over rows is
- *   the bias gradient of linear1; every entry is written (no zero-fill needed), fixed order.
+ *   colpart [mgx_gemm_nt_dfac_colpart_rows(M,N), N] fp32 (may be NULL) = partial column sums of the rounded C, two
+ *   rows per row tile (one per wave row; the row tile is 256 rows, or 128 where 256-row tiles would leave a quarter
+ *   of the chip idle - which is why the row count is a function and not a formula): their sum over rows is the bias
+ *   gradient of linear1; exactly mgx_gemm_nt_dfac_colpart_floats(M,N) = rows * N floats are written, every one of
+ *   them (no zero-fill needed), fixed order.
  *   dbias [N] fp32 (may be NULL; needs colpart): that sum, formed by a second small launch in a fixed order. */
+int mgx_gemm_nt_dfac_colpart_rows(int M, int N);
 long mgx_gemm_nt_dfac_colpart_floats(int M, int N);
 int mgx_gemm_nt_dfac_bf16(const void* A, const void* Bt, const void* fac, void* C, float* colpart, float* dbias, int M,
                           int N, int K, int lda, int ldb, int ldc, void* stream);

@@ -10,6 +10,19 @@ void mgx_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// Per-device cache of the CU count: immutable once written (every writer stores the same value), so concurrent first
+// calls are benign.
+int mgx_cu_count() {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (dev >= 0 && dev < 64 && cache[dev] > 0) return cache[dev];
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    if (dev >= 0 && dev < 64) cache[dev] = prop.multiProcessorCount;
+    return prop.multiProcessorCount;
+}
+
 extern "C" int mgx_version(void) { return 100; }
 extern "C" const char* mgx_last_error_string(void) { return g_err; }
 

@@ -430,13 +430,8 @@ int mgx_attn_bwd_dq_pipe(const void* dout, const void* qkv, const float* lse, co
     a.nqb = (S + 127) / 128;
     a.np = (a.nqb + 1) / 2;
     a.nwork = B * H * a.np;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MGX_ELAUNCH;
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = mgx_cu_count();
+    MGX_REQUIRE(n_cu > 0, MGX_ELAUNCH, "attention backward: cannot query the device");
     // Persistent workgroups, one resident per CU (registers), TWO per CU in the grid: the second half is handed out by
     // the dispatcher as CUs come free.  On an idle chip that costs nothing measurable (639 against 641 us per backward);
     // when another kernel holds some CUs -- RCCL's reduction kernels during the data-parallel backward -- the work

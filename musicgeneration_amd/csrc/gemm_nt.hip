@@ -455,10 +455,11 @@ static int nt_check(const char* fn, const void* A, const void* Bt, const void* C
     return MGX_OK;
 }
 
-// 128-row tiles where 256-row tiles would fill at most three quarters of the chip's 256 CUs
+// 128-row tiles where 256-row tiles would fill at most three quarters of the current device's CUs (256 on MI355X)
 static inline bool nt_half_tiles(int M, int N) {
     const long nblk = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    return nblk <= 192 && M > 128;
+    const int cus = mgx_cu_count() > 0 ? mgx_cu_count() : 256;
+    return 4 * nblk <= 3L * cus && M > 128;
 }
 static inline long nt_blocks(int M, int N) {
     const int bm = nt_half_tiles(M, N) ? 128 : BM;
@@ -493,7 +494,11 @@ extern "C" int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2
     return MGX_OK;
 }
 
-extern "C" long mgx_gemm_nt_dfac_colpart_floats(int M, int N) { return (long)((M + 127) / 128) * 2 * N; }
+// rows of colpart a call writes: two per row tile (one per wave row), the row tile being 128 or 256 rows
+extern "C" int mgx_gemm_nt_dfac_colpart_rows(int M, int N) {
+    return 2 * (nt_half_tiles(M, N) ? (M + 127) / 128 : (M + BM - 1) / BM);
+}
+extern "C" long mgx_gemm_nt_dfac_colpart_floats(int M, int N) { return (long)mgx_gemm_nt_dfac_colpart_rows(M, N) * N; }
 
 extern "C" int mgx_gemm_nt_dfac_bf16(const void* A, const void* Bt, const void* fac, void* C, float* colpart, float* dbias,
                                      int M, int N, int K, int lda, int ldb, int ldc, void* stream) {
@@ -506,7 +511,7 @@ extern "C" int mgx_gemm_nt_dfac_bf16(const void* A, const void* Bt, const void* 
     NT_LAUNCH(EPI_DFAC, 0, false);
     MGX_CHECK_LAUNCH("gemm_nt_dfac");
     if (dbias) {
-        const int rows = 2 * (nt_half_tiles(M, N) ? (M + 127) / 128 : (M + BM - 1) / BM);
+        const int rows = mgx_gemm_nt_dfac_colpart_rows(M, N);
         hipLaunchKernelGGL(nt_colpart_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, (hipStream_t)stream, colpart,
                            dbias, rows, N);
         MGX_CHECK_LAUNCH("gemm_nt_dfac_reduce");

@@ -353,10 +353,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }  // namespace
 
 static long tn_tiles(int M, int N) { return (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN); }
-// one workgroup per CU (128 KiB of LDS each) and equal work per workgroup: a single round of at most 256
-// workgroups has no tail and writes the fewest fp32 slabs
+// one workgroup per CU (128 KiB of LDS each) and equal work per workgroup: a single round of at most one workgroup
+// per CU of the current device (256 on MI355X) has no tail and writes the fewest fp32 slabs
 static int tn_splits(long tiles, int K) {
-    int splits = (int)(256 / tiles);
+    const int cus = mgx_cu_count() > 0 ? mgx_cu_count() : 256;
+    int splits = (int)(cus / tiles);
     const int max_splits = (K + 4 * BK - 1) / (4 * BK);     // at least 4 K tiles per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

@@ -16,6 +16,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 void mgx_set_error(const char* fmt, ...);
+// compute units of the CURRENT device (looked up once per device, api.hip); <= 0 on failure
+int mgx_cu_count();
 
 #define MGX_REQUIRE(cond, code, ...)            \
     do {                                        \

@@ -30,7 +30,7 @@ class RelativeAttention(Attention):
     def forward(self, x, mask=None):
         """Stand-alone path; `mask` ignored (causal inside the kernel)."""
         qkv = self.c_attn(x)
-        a = torch.ops.mgx.rel_attention(qkv.contiguous(), self.E.to(qkv.dtype), self.heads)[0]    # torch_ops.py
+        a = torch.ops.mgx.rel_attention(qkv.contiguous(), self.E, self.heads)[0]    # torch_ops.py: fp32 dE reaches the master
         return self.c_proj(a)
 
 

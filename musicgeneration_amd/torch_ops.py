@@ -118,8 +118,10 @@ alibi_attention.register_autograd(_alibi_backward, setup_context=_alibi_setup)
 
 @_lib.custom_op("mgx::rel_attention", mutates_args=())
 def rel_attention(qkv: Tensor, E: Tensor, n_heads: int) -> Tuple[Tensor, Tensor]:
-    """Skew relative attention; E in the compute dtype.  Returns (out, lse)."""
-    return ops.rel_attn_fwd(qkv, E, n_heads)
+    """Skew relative attention.  E: the table in the compute dtype, or the fp32 master (cast here): the gradient the
+    autograd formula returns has E's dtype, so handing in the master keeps the kernel's fp32 dE unrounded.
+    Returns (out, lse)."""
+    return ops.rel_attn_fwd(qkv, E if E.dtype == qkv.dtype else E.to(qkv.dtype), n_heads)
 
 
 @rel_attention.register_fake
@@ -138,7 +140,8 @@ def _rel_setup(ctx, inputs, output):
 
 def _rel_backward(ctx, dout, _dlse):
     qkv, out, lse, E = ctx.saved_tensors
-    dqkv, dE = torch.ops.mgx.rel_attn_bwd(dout.contiguous(), qkv, out, lse, E, ctx.n_heads)
+    Ec = E if E.dtype == qkv.dtype else E.to(qkv.dtype)
+    dqkv, dE = torch.ops.mgx.rel_attn_bwd(dout.contiguous(), qkv, out, lse, Ec, ctx.n_heads)
     return dqkv, dE.to(E.dtype), None
 
 

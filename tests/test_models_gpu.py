@@ -740,3 +740,151 @@ def test_shadow_cache_follows_replaced_parameters():
         t = c.pair(p, torch.bfloat16, (64, 64), True)
         assert float(s[0, 0]) == float(trial) and float(a[3, 5]) == float(trial) and float(t[5, 3]) == float(trial)
         del p, s, a, t                                     # the next Parameter often reuses this id
+
+
+def test_full_size_properties_of_the_separated_configuration():
+    """BASELINE configs[2] at its real depth and shape (alibi_separated 256/256/512 -> d=1024, L=10, H=8, ff=4096, bf16,
+    batch 8 x seq 1024 per GPU: M = 8192 token rows, so the 1024-column projections take the 128-row tiles of
+    gemm_nt_kernel<..., HALF>), where the oracle is too slow: size-independent properties of the same kernels.
+      * the host picks the half-tile path for these shapes (the C ABI reports the partial-sum rows it will write);
+      * determinism: two forward+backward passes give bit-identical logits and gradients;
+      * causality: changing tokens at positions >= p leaves the logits of positions < p bit-identical;
+      * targets with class weight 0 (token 1 of the note / velocity rows) and the ignore_index of the duration row
+        carry no gradient into the logits; the other targets do."""
+    from musicgeneration_amd import _lib
+    from musicgeneration_amd.model_baseline import build_everything_separated as cfg
+    from musicgeneration_amd.synthetic import SyntheticSeparatedDataset
+    B, S = 8, 1024
+    assert _lib.lib.mgx_gemm_nt_dfac_colpart_rows(B * S, 1024) == 2 * (B * S // 128)      # 128-row tiles (HALF)
+    assert _lib.lib.mgx_gemm_nt_dfac_colpart_rows(B * S, 4096) == 2 * (B * S // 256)      # 256-row tiles
+    args = cfg.m_args.get_copy()
+    args.dtype = "bf16"
+    args.dropout = 0.0
+    torch.manual_seed(21)
+    model, crit = cfg.build_model_and_criterion(args)
+    model, crit = model.cuda().train(), crit.cuda()
+    x, y = SyntheticSeparatedDataset(B, S, seed=22, device="cuda").get()
+    y = y.clone()
+    y[:, :, -64:] = 1                                           # a tail of end tokens: weight 0 / ignore_index
+
+    def run(xx):
+        model.zero_grad(set_to_none=True)
+        pred = model(xx)
+        loss, parts = crit(pred, y)
+        loss.backward()
+        return [p.detach().clone() for p in pred], {n: p.grad.detach().clone() for n, p in model.named_parameters()}, \
+            float(loss.detach())
+
+    l1, g1, loss1 = run(x)
+    l2, g2, loss2 = run(x)
+    assert np.isfinite(loss1) and loss1 == loss2
+    assert [tuple(t.shape) for t in l1] == [(B, S, 92), (B, S, 130), (B, S, 203)]
+    for a, b in zip(l1, l2):
+        assert torch.equal(a, b)
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n
+        assert torch.isfinite(g1[n]).all(), n
+    p = 768                                                     # a wave's 32-query boundary
+    x2 = x.clone()
+    x2[:, :, p:] = SyntheticSeparatedDataset(B, S, seed=23, device="cuda").get()[0][:, :, p:]
+    l3, _, _ = run(x2)
+    for a, b in zip(l1, l3):
+        assert torch.equal(a[:, :p], b[:, :p])
+    assert any(not torch.equal(a[:, p:], b[:, p:]) for a, b in zip(l1, l3))
+    # no gradient from weight-0 / ignored targets
+    pred = [t.detach().requires_grad_(True) for t in model(x)]
+    loss, _ = crit(tuple(pred), y)
+    loss.backward()
+    for t in pred:
+        assert float(t.grad[:, -64:].abs().max()) == 0.0
+        assert float(t.grad[:, :-64].abs().max()) > 0.0
+
+
+def test_training_loop_mixed_precision_with_a_bucketer(tmp_path):
+    """train_utils.training_loop as build_everything_separated.py:97 runs it (mixed_precision=True: bf16 autocast
+    policy, disabled GradScaler kept for the checkpoint key) with ddp=GradientBucketer (one RCCL rank on this GPU) and
+    FusedAdamW: the loss falls on a repeating batch, the checkpoint keeps the reference's keys, close() detaches."""
+    import os
+    import torch.distributed as dist
+    from musicgeneration_amd import ops, train_utils as tu
+    from musicgeneration_amd.data_parallel import GradientBucketer
+    from musicgeneration_amd.model_baseline.alibi_separated import AlibiTransformer, Criterion, Metrics
+    from musicgeneration_amd.optim import FusedAdamW
+    from musicgeneration_amd.synthetic import SyntheticSeparatedDataset
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29535")
+    dev = torch.device("cuda", 0)
+    started = not dist.is_initialized()
+    if started:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(0)
+        m = AlibiTransformer(92, 130, 203, 32, 32, 64, 2, 2, 128, 256, dropout=0.1).to(dev)     # d=128, dh=64
+        crit = Criterion(92, 130, 203).to(dev)
+        opt = FusedAdamW(m.parameters(), lr=3e-3, weight_decay=1e-4)
+        sched = torch.optim.lr_scheduler.StepLR(opt, 50)
+
+        class Repeat:
+            def __init__(self):
+                self.b = SyntheticSeparatedDataset(4, 128, seed=5, device="cuda").get()
+            def __len__(self):
+                return 30
+            def get(self):
+                return tuple(t.cpu().numpy() for t in self.b)
+
+        logger = tu.Logger(None, Metrics())
+        with GradientBucketer(m, bucket_mb=0.05) as ddp:
+            assert len(ddp.buckets) > 2
+            n = tu.training_loop(m, Repeat(), crit, opt, sched, logger, log_scalar_metric_step=40, checkpoint_step=60,
+                                 epochs=1, batch_size=4, run_dir=str(tmp_path), mixed_precision=True, ddp=ddp, sync_every=4)
+            # the bf16 policy ran (the block weights were shadowed in bf16) and the gradients sit in their bucket slots
+            assert all(p.grad.data_ptr() == p.mgx_grad_slot.data_ptr() for p in m.parameters())
+        assert n == 120
+        assert ops.LOSS_DENOMINATOR_HOOK is None and not hasattr(next(m.parameters()), "mgx_grad_slot")
+        losses = [h[1]["train/loss"] for h in logger.history]
+        assert len(losses) >= 2 and losses[-1] < losses[0], losses
+        state = torch.load(tu.get_checkpoints(str(tmp_path))[-1], map_location="cpu", weights_only=True)
+        assert set(state.keys()) == {"model", "optmizer", "grad_scaler", "criterion", "lr_scheduler", "steps"}
+        assert "mask" in state["model"] and {"weight_n", "weight_v"} <= set(state["criterion"].keys())
+    finally:
+        if started:
+            dist.destroy_process_group()
+
+
+def test_shared_block_gets_its_bucket_slot_once_per_backward():
+    """A decoder block applied twice in one graph (shared weights): both backward nodes produce gradients for the
+    same parameters.  ops.grad_slot hands the parameter's bucket slot to the first producer only; autograd adds the
+    second gradient, so p.grad is the sum of both (not twice the last one)."""
+    import os
+    import torch.distributed as dist
+    from musicgeneration_amd.data_parallel import GradientBucketer
+    from musicgeneration_amd.model_baseline.alibi_unified import AlibiTransformer, Criterion
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29537")
+    dev = torch.device("cuda", 0)
+    started = not dist.is_initialized()
+    if started:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        def build():
+            torch.manual_seed(7)
+            m = AlibiTransformer(vocab=96, embed_dim=128, n_layers=2, n_heads=2, max_sequence=256, proj_forward=256,
+                                 dropout=0.0, dtype="bf16").to(dev)
+            m.decoder_layers[1] = m.decoder_layers[0]                # the same block twice
+            return m
+        g = torch.Generator().manual_seed(3)
+        x = torch.randint(2, 96, (2, 192), generator=g).to(dev)
+        y = torch.randint(2, 96, (2, 192), generator=g).to(dev)
+        crit = Criterion().to(dev)
+        ref = build()
+        crit(ref(x), y)[0].backward()
+        m = build()
+        with GradientBucketer(m, mode="flat") as ddp:
+            crit(m(x), y)[0].backward()
+            ddp.finish()
+            torch.cuda.synchronize()
+            for (n1, p1), (_, p2) in zip(m.named_parameters(), ref.named_parameters()):
+                assert gu.rel_err(p1.grad, p2.grad) < 1e-6, n1
+    finally:
+        if started:
+            dist.destroy_process_group()
