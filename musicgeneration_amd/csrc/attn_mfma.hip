@@ -33,21 +33,31 @@ namespace {
 // ===========================================================================
 // forward
 // ===========================================================================
+constexpr int FWD_GROUP = 8;        // (batch, head) pairs whose query blocks an XCD runs together
+
 template <int DH, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv,
                                                                 const float* __restrict__ slopes,
                                                                 bf16_t* __restrict__ out, float* __restrict__ lse,
-                                                                int S, int H, float c /* scale*log2e */) {
+                                                                int S, int H, float c /* scale*log2e */, int npairs) {
     constexpr int NT = 64 * NW, QB = 32 * NW, TB = Img<DH>::TILE_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[4 * TB];      // 2 buffers x (K image, V image)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, h5 = lane >> 5;
-    // grid = (H, B, q-blocks): the q-block index is the slowest dispatch dimension, so ALL the heavy
-    // (late, long-context) blocks start first and the tail of the launch is made of the lightest ones;
-    // blocks of one (b,h) are 8k apart in dispatch order, i.e. on one XCD (shared K/V in its L2).
-    const int qb = gridDim.z - 1 - blockIdx.z;
+    // 1-D grid; workgroup n runs on XCD n & 7 (round-robin dispatch).  An XCD walks its (batch, head) pairs in groups
+    // of FWD_GROUP: inside a group the query blocks heaviest first, the group's pairs fastest - so the blocks in flight
+    // on an XCD (64 workgroups) belong to 8 pairs whose K/V (1 MB each at S 2048, dh 128) they share through its L2
+    // (the (H, B, q-block) grid of rounds 1-2 had 16 pairs x 4 blocks in flight: 205 -> 200 us), and the dispatcher's
+    // first-free-slot order still ends every slot at the same time (list-scheduling the 4..32-tile blocks of 16 pairs
+    // on 64 slots in this order: makespan 36 tiles = the ideal; pair-major order: 56).
+    const int nqb = (S + QB - 1) / QB;
+    const int xcd = blockIdx.x & 7, sl = blockIdx.x >> 3;
+    const int grp = sl / (FWD_GROUP * nqb), r_ = sl % (FWD_GROUP * nqb);
+    const int qb = nqb - 1 - r_ / FWD_GROUP;
+    const int pair = 8 * (grp * FWD_GROUP + r_ % FWD_GROUP) + xcd;
+    if (pair >= npairs) return;                          // whole workgroups; before any barrier
+    const int b = pair / H, h = pair % H;
     const int q0 = qb * QB, qw0 = q0 + 32 * w;
-    const int b = blockIdx.y, h = blockIdx.x;
     const unsigned rs = 3u * H * DH;
     const bf16_t* base = qkv + (long)b * S * rs + (long)h * DH;
     const bf16_t* kp = base + (long)H * DH;
@@ -220,13 +230,16 @@ int mgx_attn_fwd_mfma(int mode, const void* qkv, const float* slopes, const void
     MGX_REQUIRE(mode == 0, MGX_EUNSUPPORTED, "mgx_attn_fwd_mfma: mode %d", mode);
     const float c = LOG2E / sqrtf((float)dh);
     constexpr int NW = 8;                                // waves (x 32 queries) per workgroup
-    dim3 grid(H, B, (S + 32 * NW - 1) / (32 * NW));
+    const int nqb = (S + 32 * NW - 1) / (32 * NW);
+    const long ppx = ((B * H + 7) / 8 + FWD_GROUP - 1) / FWD_GROUP * FWD_GROUP;       // pair slots per XCD
+    MGX_REQUIRE(8 * ppx * nqb < (1L << 31), MGX_EUNSUPPORTED, "mgx_attn_fwd_mfma: too many workgroups");
+    dim3 grid((unsigned)(8 * ppx * nqb), 1, 1);
     if (dh == 64)
         hipLaunchKernelGGL((attn_fwd_mfma_kernel<64, NW>), grid, dim3(64 * NW), 0, st, (const bf16_t*)qkv, slopes,
-                           (bf16_t*)out, lse, S, H, c);
+                           (bf16_t*)out, lse, S, H, c, B * H);
     else
         hipLaunchKernelGGL((attn_fwd_mfma_kernel<128, NW>), grid, dim3(64 * NW), 0, st, (const bf16_t*)qkv, slopes,
-                           (bf16_t*)out, lse, S, H, c);
+                           (bf16_t*)out, lse, S, H, c, B * H);
     MGX_CHECK_LAUNCH("attn_fwd_mfma");
     return MGX_OK;
 }

@@ -60,6 +60,19 @@ struct TileRegs {
     bf16x8 v[8 * DH / NT];
 };
 
+// Which 16-byte piece (row, chunk) of the tile thread element e moves.  Eight consecutive lanes - the unit a
+// ds_write_b128 is serviced in - take chunks c..c+3 of an even row and the same chunks of the next row: 2 x 64 bytes on
+// banks 0-15 and 16-31.  (Eight chunks of ONE row land on 16 banks twice, the image keeps chunk groups 512 B apart:
+// every staging store was a 2-way conflict, 4.72 M extra LDS cycles per forward launch at B16 S2048 H8 dh128,
+// profiles/r02b_step_sq.txt.)  A wave-instruction still covers whole 128-byte lines of 4 (dh 128) or 8 (dh 64) rows.
+template <int DH>
+__device__ __forceinline__ void tile_elem(int e, int& row, int& ch) {
+    constexpr int BLK = 2 * Img<DH>::CPR;
+    const int u = e % BLK;
+    row = 2 * (e / BLK) + ((u >> 2) & 1);
+    ch = (u & 3) | ((u >> 3) << 2);
+}
+
 // Rows past the end are clamped to row S-1 instead of zero-filled: every consumer multiplies them
 // by an exactly-zero probability (causal mask / -inf row statistic), so real finite data is as good
 // as zeros and the load needs no branch.  Offsets are 32-bit (launchers check S*row_bytes < 2^31).
@@ -67,8 +80,8 @@ template <int DH, int NT>
 __device__ __forceinline__ void tile_load(TileRegs<DH, NT>& t, const bf16_t* src, unsigned rs, int r0, int S, int tid) {
 #pragma unroll
     for (int n = 0; n < 8 * DH / NT; ++n) {
-        const int e = tid + NT * n;
-        const int row = e / Img<DH>::CPR, ch = e % Img<DH>::CPR;
+        int row, ch;
+        tile_elem<DH>(tid + NT * n, row, ch);
         const unsigned g = (unsigned)min(r0 + row, S - 1);
         t.v[n] = *reinterpret_cast<const bf16x8*>(src + (g * rs + (unsigned)(ch * 8)));
     }
@@ -77,8 +90,8 @@ template <int DH, int NT>
 __device__ __forceinline__ void tile_store(const TileRegs<DH, NT>& t, char* img, int tid) {
 #pragma unroll
     for (int n = 0; n < 8 * DH / NT; ++n) {
-        const int e = tid + NT * n;
-        const int row = e / Img<DH>::CPR, ch = e % Img<DH>::CPR;
+        int row, ch;
+        tile_elem<DH>(tid + NT * n, row, ch);
         *reinterpret_cast<bf16x8*>(img + Img<DH>::off(row, ch)) = t.v[n];
     }
 }
