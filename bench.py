@@ -425,6 +425,18 @@ def bench_decode(a, device, rank, world, B, new):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    # the stochastic branch (inference_unified.py:16-17; SURVEY 8(d) Cfg 4 "greedy + multinomial"): same graph with the
+    # counter-based Gumbel-max draw in the head kernel
+    seq_s = seq0.clone()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    sample_next_plus_one(model, seq_s, idx=64, deterministic=False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt_s = time.perf_counter() - t1
     gc.unfreeze()
     # second, untimed-for-`value` pass over the head of the same continuation, launch by launch, with a HIP-event
     # pair around every decode-attention launch (a graph replay cannot be bracketed per kernel)
@@ -436,9 +448,9 @@ def bench_decode(a, device, rank, world, B, new):
     events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
     same = bool(torch.equal(seq1[:, :-1], seq[:, :64 + ev_new]))
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt, dt_s], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        dt, dt_s = float(t[0]), float(t[1])
     steps = L - 1 - 64
     value = world * B * steps / dt
     esz = 2 if a.dtype == "bf16" else 4
@@ -464,6 +476,9 @@ def bench_decode(a, device, rank, world, B, new):
     return {"metric": "decode tokens/sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": 16,
             "step_bytes": step_bytes, "step_gb_per_s": step_gbs, "step_frac_of_hbm_peak": step_gbs / PEAK_HBM_GBS,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "stochastic": {"value": world * B * steps / dt_s, "unit": "tokens/s", "ms_per_step": dt_s / steps * 1e3,
+                           "draw": "deterministic=False: Gumbel-max over softmax(logits) in the head kernel, counter-based RNG, "
+                                   "same HIP graph", "tokens_in_vocab": bool(int(seq_s.max()) < 618 and int(seq_s.min()) >= 0)},
             "dtype": a.dtype, "data": "synthetic primer, random-init weights",
             "config": {"workload": f"decode_unified: alibi_unified d={d} L={Ln}, batch {B}/GPU, {steps}-token greedy "
                                    f"continuation from a 63-token primer, KV cache", "global_batch": world * B,

@@ -208,6 +208,25 @@ int mgx_decode_head_argmax(const void* h, int B, int R, int d, const float* gamm
 int mgx_decode_commit(void* seq, int seq_is_int64, long L, int B, int* pos_dev, unsigned long long* keys,
                       void* stream);
 
+/* The same three steps for n token streams (n <= 4; n = 3: the separated model's note | velocity | duration rows,
+ * inference_separated.py:18-28; n = 1: the unified model) and for the stochastic branch (inference_unified.py:16-17:
+ * `multinomial(softmax(n[:, i+1]), 1)`):
+ *   seq [B,n,L]; tables[k] fp32 [V[k], d[k]] (HOST arrays of device pointers / ints), out bf16 [B,R,sum d[k]]
+ *                (alibi_separated.py:135-139: three gathers + cat);
+ *   W [sum V[k], d] bf16 = the output heads stacked (alibi_separated.py:151-154), bias [sum V[k]] fp32, keys [B,n];
+ *   stochastic != 0: head k's class is argmax_c(logit_c + G_c), G_c standard Gumbel noise from a counter-based hash of
+ *                (seed, *pos_dev, b, c): a draw from softmax(logits) (Gumbel-max), reproducible per seed, no host
+ *                generator state, so the step still replays as a HIP graph; not torch.multinomial's stream.
+ *   commit: seq[b,k,pos+1] = class of keys[b,k]; keys = 0; pos += 1. */
+int mgx_sample_gather_embed(const void* seq, int seq_is_int64, long L, const int* pos_dev, int n,
+                            const float* const* tables, const int* V, const int* d, int B, int R, void* out,
+                            void* stream);
+int mgx_sample_head(const void* h, int B, int R, int d, const float* gamma, const float* beta, float eps,
+                    const void* W, const float* bias, int n, const int* V, int stochastic, unsigned long long seed,
+                    const int* pos_dev, unsigned long long* keys, float* logits, void* stream);
+int mgx_sample_commit(void* seq, int seq_is_int64, long L, int B, int n, int* pos_dev, unsigned long long* keys,
+                      void* stream);
+
 /* Token embedding for training: out[T,d] bf16 = table[tokens[t], :] (fp32 [V,d]) rounded to nearest even:
  * `self.embed(x)` + the autocast cast in one pass (alibi_unified.py:130-131).  tokens int64 [T], clamped to [0, V). */
 int mgx_embed_rows_bf16(const long long* tokens, const float* table, int V, int d, long T, void* out, void* stream);

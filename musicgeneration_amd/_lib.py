@@ -52,6 +52,9 @@ PROTOTYPES = {
     "mgx_decode_gather_embed": (_i, [_vp, _i, _l, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mgx_decode_head_argmax": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _vp]),
     "mgx_decode_commit": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp]),
+    "mgx_sample_gather_embed": (_i, [_vp, _i, _l, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "mgx_sample_head": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _vp, _i, _u64, _vp, _vp, _vp, _vp]),
+    "mgx_sample_commit": (_i, [_vp, _i, _l, _i, _i, _vp, _vp, _vp]),
     "mgx_embed_rows_bf16": (_i, [_vp, _vp, _i, _i, _l, _vp, _vp]),
     "mgx_embed_cat_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "mgx_colsum_workspace_floats": (_l, [_i]),

@@ -1,10 +1,14 @@
-// Head and tail of one greedy sampling step of the unified model (inference_unified.py:14-20), bf16:
-//   mgx_decode_gather_embed   seq[:, pos .. pos+R-1] -> embedding rows -> bf16 [B,R,d]
-//                             (seq.index_select + F.embedding + .to(dtype): alibi_unified.py:130-131)
-//   mgx_decode_head_argmax    row R-1 of the trunk output -> Norm (base_layers.py:36-41) -> proj_class
-//                             (alibi_unified.py:136-137) -> running argmax per sequence (inference_unified.py:18)
-//   mgx_decode_commit         seq[:, pos+1] = argmax, pos += 1 (inference_unified.py:19-20; the reference draws
-//                             token i from the logits of row i+1)
+// Head and tail of one sampling step (inference_unified.py:14-20, inference_separated.py:20-27), bf16, for one token
+// stream (unified) or several (separated: note | velocity | duration), greedy or stochastic:
+//   mgx_sample_gather_embed   seq[:, (k,) pos .. pos+R-1] -> embedding rows (concatenated over streams) -> bf16 [B,R,d]
+//                             (seq.index_select + F.embedding (+ cat) + .to(dtype): alibi_unified.py:130-131,
+//                             alibi_separated.py:135-139)
+//   mgx_sample_head           row R-1 of the trunk output -> Norm (base_layers.py:36-41) -> the stacked output heads
+//                             (alibi_unified.py:136-137, alibi_separated.py:151-154) -> per sequence and head the
+//                             running argmax (inference_unified.py:18) or a Gumbel-max draw (:16-17)
+//   mgx_sample_commit         seq[:, (k,) pos+1] = drawn class, pos += 1 (inference_unified.py:19-20; the reference
+//                             draws token i from the logits of row i+1)
+// mgx_decode_gather_embed / _head_argmax / _commit are the one-stream greedy forms of the same kernels.
 // Three launches instead of the ~14 tiny library kernels (index arithmetic, gather, casts, LayerNorm over all
 // rows, a 192 x 618 GEMM, slice, argmax, scatter) that made ~50 us of every 1 ms step.  The position lives in
 // device memory, so the step replays as a HIP graph.  Integer results are exact; logits are the bf16-rounded
@@ -13,20 +17,31 @@
 
 namespace {
 
-// one workgroup per (b, r) row
+// several token streams (alibi_separated.py:135-139) or one (alibi_unified.py:130): tables and widths by value
+struct EmbedCat {
+    const float* table[4];
+    int V[4], d[4];
+    int n;
+};
+
+// one workgroup per (b, r) row; seq [B, n, L]: stream k of sequence b is row b*n + k
 __global__ __launch_bounds__(256) void gather_embed_kernel(const void* __restrict__ seq, int seq_i64, long L,
-                                                            const int* __restrict__ pos, const float* __restrict__ table,
-                                                            int V, int d, int R, bf16_t* __restrict__ out) {
+                                                            const int* __restrict__ pos, EmbedCat e, int D, int R,
+                                                            bf16_t* __restrict__ out) {
     const int b = blockIdx.x / R, r = blockIdx.x % R;
-    const long at = (long)b * L + min((long)(*pos + r), L - 1);
-    long tok = seq_i64 ? reinterpret_cast<const long*>(seq)[at] : (long)reinterpret_cast<const int*>(seq)[at];
-    tok = min(max(tok, 0L), (long)V - 1);                 // F.embedding would raise; a sampling buffer never holds these
-    const float* src = table + tok * d;
-    bf16_t* dst = out + (long)blockIdx.x * d;
-    for (int c = threadIdx.x * 4; c < d; c += 1024) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
-        const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-        *reinterpret_cast<bf16x4*>(dst + c) = o;
+    const long col = min((long)(*pos + r), L - 1);
+    bf16_t* dst = out + (long)blockIdx.x * D;
+    for (int k = 0; k < e.n; ++k) {
+        const long at = ((long)b * e.n + k) * L + col;
+        long tok = seq_i64 ? reinterpret_cast<const long*>(seq)[at] : (long)reinterpret_cast<const int*>(seq)[at];
+        tok = min(max(tok, 0L), (long)e.V[k] - 1);        // F.embedding would raise; a sampling buffer never holds these
+        const float* src = e.table[k] + tok * e.d[k];
+        for (int c = threadIdx.x * 4; c < e.d[k]; c += 1024) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+            const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            *reinterpret_cast<bf16x4*>(dst + c) = o;
+        }
+        dst += e.d[k];
     }
 }
 
@@ -50,11 +65,6 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const long* __restrict_
 
 // several token streams x [B, n, S] -> concat_k bf16(table_k[x[b, k, s], :]) as rows of out [B*S, sum d_k]
 // (alibi_separated.py:135-139: three F.embedding gathers + torch.cat + the autocast cast).  One wave per row.
-struct EmbedCat {
-    const float* table[4];
-    int V[4], d[4];
-    int n;
-};
 __global__ __launch_bounds__(256) void embed_cat_kernel(const long* __restrict__ tokens, EmbedCat e, int B, int S, int D,
                                                          bf16_t* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -82,20 +92,49 @@ __device__ __forceinline__ unsigned long long argmax_key(float v, int idx) {
     return ((unsigned long long)u << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)idx);   // ties: the lower index wins
 }
 
+// Output heads stacked in one weight: head k owns classes [off[k], off[k+1]) of W / bias (alibi_separated.py:151-154:
+// note | velocity | duration; n = 1 for the unified model).
+struct SampleHeads {
+    int n;
+    int off[5];
+};
+
+// Standard Gumbel noise from a counter: (seed, step, element) -> 64-bit mix (splitmix64 finaliser) -> u in (0,1) with
+// 32 random bits -> -log(-log u).  argmax_c(logit_c + G_c) is a draw from softmax(logits) (the Gumbel-max identity):
+// torch.multinomial(softmax(n[:, i+1]), 1) of inference_unified.py:16-17 without the normalisation, the prefix sum,
+// or host-side generator state, so the step still replays as a graph.  The stream differs from torch's (it must: the
+// reference's generator is host state), the distribution is the same.
+__device__ __forceinline__ float gumbel_noise(unsigned long long seed, unsigned step, unsigned long long elem) {
+    unsigned long long x = seed ^ ((unsigned long long)(step + 1u) * 0x9E3779B97F4A7C15ull) ^ (elem * 0xD1B54A32D192ED03ull);
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    const float u = ((float)(unsigned)(x >> 40) + 0.5f) * (1.0f / 16777216.0f);      // 24 bits: exact in fp32, never 0 or 1
+    const unsigned lo = (unsigned)x & 0xFFu;                                          // 8 more bits for the tails
+    const float u2 = u + ((float)lo - 127.5f) * (1.0f / 4294967296.0f);
+    return -__logf(-__logf(fminf(fmaxf(u2, 1.0e-10f), 0.99999994f)));
+}
+
 // grid (VC, B), 4 waves.  Every workgroup normalises row R-1 of sequence b itself (d <= 2048 values: cheaper than
 // a launch boundary), then its waves walk the classes of chunk blockIdx.x: four classes per wave per pass, a
-// weight row read as two 16-byte loads per lane per 1024 columns.  keys[b] must be 0 on entry (mgx_decode_commit
-// leaves it so).  logits (optional) [B,V] fp32.
+// weight row read as two 16-byte loads per lane per 1024 columns.  keys[b, k] (one per head) must be 0 on entry
+// (the commit kernel leaves them so).  logits (optional) [B,V] fp32.  stochastic: the keys order logit + Gumbel noise
+// keyed by (seed, *pos, b * V + class) instead of the logit.
 template <int NV>   // d <= 1024 * NV: every thread normalises 4 * NV columns
 __global__ __launch_bounds__(256) void head_argmax_kernel(const bf16_t* __restrict__ h, int R, int d,
                                                            const float* __restrict__ g, const float* __restrict__ be,
                                                            float eps, const bf16_t* __restrict__ W,
                                                            const float* __restrict__ bias, int V, int vper,
+                                                           SampleHeads hd, int stochastic, unsigned long long seed,
+                                                           const int* __restrict__ pos,
                                                            unsigned long long* __restrict__ keys,
                                                            float* __restrict__ logits) {
     __shared__ __attribute__((aligned(16))) bf16_t y[256 * 4 * NV];
     __shared__ float red[8];
     __shared__ unsigned long long best[4];
+    if (threadIdx.x < 4) best[threadIdx.x] = 0;
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bf16_t* x = h + ((long)b * R + (R - 1)) * d;
     // LayerNorm as ln_fwd_kernel: fp32 mean, biased variance of the deviations, result rounded to bf16
@@ -148,7 +187,7 @@ __global__ __launch_bounds__(256) void head_argmax_kernel(const bf16_t* __restri
     __syncthreads();
     // classes of this chunk
     const int v0 = blockIdx.x * vper, v1 = min(v0 + vper, V);
-    unsigned long long mine = 0;
+    const unsigned step = stochastic ? (unsigned)*pos : 0u;
     // four classes per pass (their weight rows' loads all in flight before the first FMA: one class at a time was a
     // chain of ~1 us memory round trips, 28 us for the launch)
     for (int c0 = v0 + 4 * w; c0 < v1; c0 += 16) {
@@ -171,28 +210,25 @@ __global__ __launch_bounds__(256) void head_argmax_kernel(const bf16_t* __restri
                 const float lg = (float)(bf16_t)(t + bias[cls]);
                 if (lane == 0) {
                     if (logits) logits[(long)b * V + cls] = lg;
-                    const unsigned long long k = argmax_key(lg, cls);
-                    mine = k > mine ? k : mine;
+                    const int hk = (cls >= hd.off[1]) + (cls >= hd.off[2]) + (cls >= hd.off[3]);
+                    const float val = stochastic ? lg + gumbel_noise(seed, step, (unsigned long long)b * V + cls) : lg;
+                    atomicMax(&best[hk], argmax_key(val, cls - hd.off[hk]));
                 }
             }
         }
     }
-    if (lane == 0) best[w] = mine;
     __syncthreads();
-    if (tid == 0) {
-        unsigned long long k = best[0];
-        for (int i = 1; i < 4; ++i) k = best[i] > k ? best[i] : k;
-        if (k) atomicMax(keys + b, k);
-    }
+    if (tid < hd.n && best[tid]) atomicMax(keys + (long)b * hd.n + tid, best[tid]);
 }
 
-// one workgroup: seq[b, pos+1] = class of keys[b]; keys[b] = 0; pos += 1 (after every thread has read it)
-__global__ __launch_bounds__(256) void commit_kernel(void* __restrict__ seq, int seq_i64, long L, int B,
+// one workgroup: seq[row, pos+1] = class of keys[row] for the B*n rows (sequence b, stream k) of seq [B, n, L];
+// keys[row] = 0; pos += 1 (after every thread has read it)
+__global__ __launch_bounds__(256) void commit_kernel(void* __restrict__ seq, int seq_i64, long L, int rows,
                                                       int* __restrict__ pos, unsigned long long* __restrict__ keys) {
     const int p = *pos;
     __syncthreads();
     const long at = min((long)p + 1, L - 1);
-    for (int b = threadIdx.x; b < B; b += 256) {
+    for (int b = threadIdx.x; b < rows; b += 256) {
         const unsigned long long k = keys[b];
         const long tok = (long)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
         if (seq_i64) reinterpret_cast<long*>(seq)[(long)b * L + at] = tok;
@@ -204,45 +240,82 @@ __global__ __launch_bounds__(256) void commit_kernel(void* __restrict__ seq, int
 
 }  // namespace
 
+extern "C" int mgx_sample_gather_embed(const void* seq, int seq_is_int64, long L, const int* pos_dev, int n,
+                                       const float* const* tables, const int* V, const int* d, int B, int R, void* out,
+                                       void* stream) {
+    MGX_REQUIRE(seq && pos_dev && tables && V && d && out, MGX_EINVAL, "mgx_sample_gather_embed: null pointer");
+    MGX_REQUIRE(n >= 1 && n <= 4 && B > 0 && R > 0 && L >= R, MGX_EINVAL, "mgx_sample_gather_embed: n=%d B=%d R=%d L=%ld", n, B, R, L);
+    EmbedCat e{};
+    e.n = n;
+    int D = 0;
+    for (int k = 0; k < n; ++k) {
+        MGX_REQUIRE(tables[k] && V[k] > 0 && d[k] > 0 && d[k] % 4 == 0, MGX_EUNSUPPORTED,
+                    "mgx_sample_gather_embed: table %d: V=%d d=%d (d must be a multiple of 4)", k, V[k], d[k]);
+        e.table[k] = tables[k];
+        e.V[k] = V[k];
+        e.d[k] = d[k];
+        D += d[k];
+    }
+    hipLaunchKernelGGL(gather_embed_kernel, dim3(B * R), dim3(256), 0, (hipStream_t)stream, seq, seq_is_int64, L, pos_dev,
+                       e, D, R, (bf16_t*)out);
+    MGX_CHECK_LAUNCH("gather_embed");
+    return MGX_OK;
+}
+
 extern "C" int mgx_decode_gather_embed(const void* seq, int seq_is_int64, long L, const int* pos_dev,
                                        const float* table, int V, int d, int B, int R, void* out, void* stream) {
-    MGX_REQUIRE(seq && pos_dev && table && out, MGX_EINVAL, "mgx_decode_gather_embed: null pointer");
-    MGX_REQUIRE(B > 0 && R > 0 && L >= R && V > 0, MGX_EINVAL, "mgx_decode_gather_embed: B=%d R=%d L=%ld V=%d", B, R, L, V);
-    MGX_REQUIRE(d > 0 && d % 4 == 0, MGX_EUNSUPPORTED, "mgx_decode_gather_embed: d=%d must be a multiple of 4", d);
-    hipLaunchKernelGGL(gather_embed_kernel, dim3(B * R), dim3(256), 0, (hipStream_t)stream, seq, seq_is_int64, L, pos_dev,
-                       table, V, d, R, (bf16_t*)out);
-    MGX_CHECK_LAUNCH("gather_embed");
+    return mgx_sample_gather_embed(seq, seq_is_int64, L, pos_dev, 1, &table, &V, &d, B, R, out, stream);
+}
+
+extern "C" int mgx_sample_head(const void* h, int B, int R, int d, const float* gamma, const float* beta, float eps,
+                               const void* W, const float* bias, int n, const int* V, int stochastic,
+                               unsigned long long seed, const int* pos_dev, unsigned long long* keys, float* logits,
+                               void* stream) {
+    MGX_REQUIRE(h && gamma && beta && W && bias && keys && V, MGX_EINVAL, "mgx_sample_head: null pointer");
+    MGX_REQUIRE(n >= 1 && n <= 4 && B > 0 && R > 0, MGX_EINVAL, "mgx_sample_head: n=%d B=%d R=%d", n, B, R);
+    MGX_REQUIRE(!stochastic || pos_dev, MGX_EINVAL, "mgx_sample_head: a stochastic draw needs the device-side step counter");
+    MGX_REQUIRE(d >= 8 && d % 8 == 0 && d <= 2048, MGX_EUNSUPPORTED, "mgx_sample_head: d=%d (multiple of 8, at most 2048)", d);
+    SampleHeads hd{};
+    hd.n = n;
+    int Vt = 0;
+    for (int k = 0; k < n; ++k) {
+        MGX_REQUIRE(V[k] > 0, MGX_EINVAL, "mgx_sample_head: head %d has %d classes", k, V[k]);
+        hd.off[k] = Vt;
+        Vt += V[k];
+    }
+    for (int k = n; k < 5; ++k) hd.off[k] = Vt;          // heads that do not exist own no class
+    const int VC = Vt >= 256 ? 16 : (Vt >= 64 ? 4 : 1);   // class chunks: B x VC workgroups
+    const int vper = (Vt + VC - 1) / VC;
+    const dim3 grid(VC, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (d <= 1024)
+        hipLaunchKernelGGL((head_argmax_kernel<1>), grid, dim3(256), 0, st, (const bf16_t*)h, R, d, gamma, beta, eps,
+                           (const bf16_t*)W, bias, Vt, vper, hd, stochastic, seed, pos_dev, keys, logits);
+    else
+        hipLaunchKernelGGL((head_argmax_kernel<2>), grid, dim3(256), 0, st, (const bf16_t*)h, R, d, gamma, beta, eps,
+                           (const bf16_t*)W, bias, Vt, vper, hd, stochastic, seed, pos_dev, keys, logits);
+    MGX_CHECK_LAUNCH("sample_head");
     return MGX_OK;
 }
 
 extern "C" int mgx_decode_head_argmax(const void* h, int B, int R, int d, const float* gamma, const float* beta, float eps,
                                       const void* W, const float* bias, int V, unsigned long long* keys, float* logits,
                                       void* stream) {
-    MGX_REQUIRE(h && gamma && beta && W && bias && keys, MGX_EINVAL, "mgx_decode_head_argmax: null pointer");
-    MGX_REQUIRE(B > 0 && R > 0 && V > 0, MGX_EINVAL, "mgx_decode_head_argmax: B=%d R=%d V=%d", B, R, V);
-    MGX_REQUIRE(d >= 8 && d % 8 == 0 && d <= 2048, MGX_EUNSUPPORTED,
-                "mgx_decode_head_argmax: d=%d (multiple of 8, at most 2048)", d);
-    const int VC = V >= 256 ? 16 : (V >= 64 ? 4 : 1);     // class chunks: B x VC workgroups
-    const int vper = (V + VC - 1) / VC;
-    const dim3 grid(VC, B);
-    hipStream_t st = (hipStream_t)stream;
-    if (d <= 1024)
-        hipLaunchKernelGGL((head_argmax_kernel<1>), grid, dim3(256), 0, st, (const bf16_t*)h, R, d, gamma, beta, eps,
-                           (const bf16_t*)W, bias, V, vper, keys, logits);
-    else
-        hipLaunchKernelGGL((head_argmax_kernel<2>), grid, dim3(256), 0, st, (const bf16_t*)h, R, d, gamma, beta, eps,
-                           (const bf16_t*)W, bias, V, vper, keys, logits);
-    MGX_CHECK_LAUNCH("head_argmax");
+    return mgx_sample_head(h, B, R, d, gamma, beta, eps, W, bias, 1, &V, 0, 0ull, nullptr, keys, logits, stream);
+}
+
+extern "C" int mgx_sample_commit(void* seq, int seq_is_int64, long L, int B, int n, int* pos_dev, unsigned long long* keys,
+                                 void* stream) {
+    MGX_REQUIRE(seq && pos_dev && keys, MGX_EINVAL, "mgx_sample_commit: null pointer");
+    MGX_REQUIRE(B > 0 && n >= 1 && n <= 4 && L >= 2, MGX_EINVAL, "mgx_sample_commit: B=%d n=%d L=%ld", B, n, L);
+    hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, seq, seq_is_int64, L, B * n, pos_dev, keys);
+    MGX_CHECK_LAUNCH("commit");
     return MGX_OK;
 }
 
 extern "C" int mgx_decode_commit(void* seq, int seq_is_int64, long L, int B, int* pos_dev, unsigned long long* keys,
                                  void* stream) {
-    MGX_REQUIRE(seq && pos_dev && keys, MGX_EINVAL, "mgx_decode_commit: null pointer");
-    MGX_REQUIRE(B > 0 && L >= 2, MGX_EINVAL, "mgx_decode_commit: B=%d L=%ld", B, L);
-    hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, seq, seq_is_int64, L, B, pos_dev, keys);
-    MGX_CHECK_LAUNCH("commit");
-    return MGX_OK;
+    return mgx_sample_commit(seq, seq_is_int64, L, B, 1, pos_dev, keys, stream);
 }
 
 extern "C" int mgx_embed_rows_bf16(const long long* tokens, const float* table, int V, int d, long T, void* out,

@@ -37,6 +37,7 @@ class KVCacheDecoder:
                         torch.zeros(batch, H, max_len, dh, dtype=self.dtype, device=self.device))
                        for _ in model.decoder_layers]
         self._ws = None                                   # fp32 split-K workspace of the decode projections
+        self._head_bias32 = None                          # separated model: the three head biases stacked, fp32
         with torch.no_grad():
             self._head_wb = tuple(t.detach() for t in model.head_weights(self.dtype))   # cast once per decoder
 
@@ -117,41 +118,65 @@ class KVCacheDecoder:
             h = h2.view(B, R, d)
         return h
 
-    def fused_greedy_supported(self, seq: torch.Tensor) -> bool:
-        """The three-launch head/tail of a greedy step (csrc/sample.hip): unified model, bf16, d <= 2048."""
+    def _sample_ends(self):
+        """(embedding tables, head class counts, stacked fp32 head bias) of the unified or the separated model."""
         m = self.model
-        return (self.dtype == torch.bfloat16 and seq.dim() == 2
-                and hasattr(m, "embed") and hasattr(m, "proj_class") and m.d_model % 8 == 0 and m.d_model <= 2048
-                and seq.dtype in (torch.int32, torch.int64) and m.embed.weight.dtype == torch.float32)
+        if hasattr(m, "embed"):
+            return (m.embed.weight,), (m.proj_class.weight.shape[0],), m.proj_class.bias.detach()
+        tables = (m.embed_note.weight, m.embed_velocity.weight, m.embed_duration.weight)
+        sizes = (m.vocab_note, m.vocab_velocity, m.vocab_duration)
+        if self._head_bias32 is None:
+            self._head_bias32 = torch.cat([m.proj_note.bias, m.proj_velocity.bias, m.proj_duration.bias], 0).detach().float()
+        return tables, sizes, self._head_bias32
+
+    def fused_step_supported(self, seq: torch.Tensor) -> bool:
+        """The three-launch head/tail of a sampling step (csrc/sample.hip): unified [B,L] or separated [B,3,L]
+        buffer, bf16, d <= 2048, fp32 embedding tables of widths that are multiples of 4."""
+        m = self.model
+        unified = seq.dim() == 2 and hasattr(m, "embed") and hasattr(m, "proj_class")
+        separated = seq.dim() == 3 and seq.shape[1] == 3 and hasattr(m, "embed_note") and hasattr(m, "proj_note")
+        if not (unified or separated) or self.dtype != torch.bfloat16:
+            return False
+        tables, _, _ = self._sample_ends()
+        return (m.d_model % 8 == 0 and m.d_model <= 2048 and seq.dtype in (torch.int32, torch.int64)
+                and all(t.dtype == torch.float32 and t.shape[1] % 4 == 0 for t in tables))
 
     @torch.no_grad()
-    def greedy_step(self, seq: torch.Tensor, pos: torch.Tensor, keys: torch.Tensor):
-        """One step of inference_unified.py:14-20 with deterministic=True, position in device memory: rows pos,
-        pos+1, pos+2 (= i-1, i, i+1) run against the caches, seq[:, pos+1] receives the argmax of the logits of
-        row pos+2, pos advances by one.  keys: zero-initialised int64 [B] scratch."""
+    def sample_step(self, seq: torch.Tensor, pos: torch.Tensor, keys: torch.Tensor, stochastic=False, seed=0):
+        """One step of inference_unified.py:14-20 / inference_separated.py:20-27 with the position in device memory:
+        rows pos, pos+1, pos+2 (= i-1, i, i+1) run against the caches; seq[:, (k,) pos+1] receives, per head, the
+        argmax of the logits of row pos+2 (deterministic) or a draw from their softmax (Gumbel-max, counter-based:
+        seed, position, sequence, class); pos advances by one.  keys: zero-initialised int64 [B, heads] scratch."""
         m = self.model
-        h = ops.decode_gather_embed(seq, pos, m.embed.weight, 3)
+        tables, sizes, bias = self._sample_ends()
+        h = ops.sample_gather_embed(seq, pos, tables, 3)
         h = self.trunk(h, pos)
-        ops.decode_head_argmax(h, m.norm.g, m.norm.b, m.norm.epsilon, self._head_wb[0], m.proj_class.bias, keys)
-        ops.decode_commit(seq, pos, keys)
+        ops.sample_head(h, m.norm.g, m.norm.b, m.norm.epsilon, self._head_wb[0], bias, sizes, keys, pos=pos,
+                        stochastic=stochastic, seed=seed)
+        ops.sample_commit(seq, pos, keys)
 
 
 class GraphedSampler:
     """One sampling step of the reference loop (inference_unified.py:14-20) recorded as a HIP graph.
 
     The step reads its position from device memory (mgx_*_at entry points), gathers the three
-    token rows i-1, i, i+1 from `seq`, runs them against the caches, draws token i (greedy) and
-    scatters it into `seq`, then advances the position: replaying the graph L-2 times is the whole
-    loop, with no host round trip and ~70 kernel launches per step folded into one submission.
-    Stochastic sampling keeps the draw outside the graph (generator state is host-side).
+    token rows i-1, i, i+1 from `seq`, runs them against the caches, draws token i and scatters it
+    into `seq`, then advances the position: replaying the graph L-2 times is the whole loop, with
+    no host round trip and ~45 kernel launches per step folded into one submission.  bf16, unified
+    and separated, greedy and stochastic all take the fused head/tail of csrc/sample.hip; the
+    stochastic draw is a counter-based Gumbel-max keyed by a seed taken from torch's generator when
+    the sampler is built (torch.manual_seed makes a run reproducible; the stream is not
+    torch.multinomial's).  fp32 (parity mode) keeps the draw in torch ops outside the graph.
     """
 
     def __init__(self, dec: KVCacheDecoder, seq: torch.Tensor, first: int, deterministic: bool, capture: bool = True):
         self.dec, self.seq, self.det = dec, seq, deterministic
         self.separated = seq.dim() == 3
         dev = seq.device
-        self.fused = deterministic and dec.fused_greedy_supported(seq)
-        self.keys = torch.zeros(seq.shape[0], dtype=torch.int64, device=dev) if self.fused else None
+        self.fused = dec.fused_step_supported(seq)
+        heads = 3 if self.separated else 1
+        self.keys = torch.zeros(seq.shape[0], heads, dtype=torch.int64, device=dev) if self.fused else None
+        self.seed = 0 if deterministic else int(torch.randint(0, 2 ** 62, (1,)).item())
         self.graph = None
         self.pos = torch.full((1,), first - 1, dtype=torch.int32, device=dev)   # position of row 0 = i-1
         self.off = torch.arange(3, device=dev)
@@ -172,7 +197,7 @@ class GraphedSampler:
     def _body(self):
         seq = self.seq
         if self.fused:
-            self.dec.greedy_step(seq, self.pos, self.keys)
+            self.dec.sample_step(seq, self.pos, self.keys, stochastic=not self.det, seed=self.seed)
             return
         idx = (self.pos.long() + self.off)                       # i-1, i, i+1
         tok = seq.index_select(-1, idx)
@@ -199,7 +224,7 @@ class GraphedSampler:
             self._body()                         # launch by launch, same kernels
         else:
             self.graph.replay()
-        if not self.det:
+        if not self.det and not self.fused:
             self._write(at=self.pos.long())      # the graph already advanced the position by one
 
 
@@ -237,8 +262,8 @@ def sample_next_plus_one(model, seq: torch.Tensor, idx: int = 1, deterministic: 
         for _ in steps:
             g.step()
         return seq
-    if deterministic and dec.fused_greedy_supported(seq) and seq.is_contiguous() and len(range(idx, L - 1)) > 0:
-        g = GraphedSampler(dec, seq, idx, True, capture=False)     # the graphed step's kernels, launch by launch
+    if dec.fused_step_supported(seq) and seq.is_contiguous() and len(range(idx, L - 1)) > 0:
+        g = GraphedSampler(dec, seq, idx, deterministic, capture=False)     # the graphed step's kernels, launch by launch
         for _ in steps:
             g.step()
         return seq

@@ -915,6 +915,70 @@ def _seq_args(seq):
     return _p(seq), int(seq.dtype == torch.int64), seq.shape[1]
 
 
+def _streams_args(seq):
+    """seq [B, L] (one stream) or [B, n, L]: (pointer, is_int64, L, B, n)."""
+    if seq.dim() not in (2, 3) or seq.dtype not in (torch.int32, torch.int64):
+        raise TypeError("seq must be [B, L] or [B, n, L], int32 or int64")
+    _need(seq, "seq")
+    n = 1 if seq.dim() == 2 else seq.shape[1]
+    if not 1 <= n <= 4:
+        raise ValueError("at most 4 token streams")
+    return _p(seq), int(seq.dtype == torch.int64), seq.shape[-1], seq.shape[0], n
+
+
+def sample_gather_embed(seq, pos, tables, R=3):
+    """bf16 embedding rows of seq[:, (k,) pos .. pos+R-1], the streams' rows concatenated (mgx_sample_gather_embed)."""
+    import ctypes as C
+    sp, i64, L, B, n = _streams_args(seq)
+    if len(tables) != n:
+        raise ValueError(f"{len(tables)} tables for {n} token streams")
+    for t in tables:
+        _need(t, "table", torch.float32)
+    D = sum(t.shape[1] for t in tables)
+    out = torch.empty(B, R, D, dtype=torch.bfloat16, device=seq.device)
+    tp = (C.c_void_p * n)(*[t.data_ptr() for t in tables])
+    Vs = (C.c_int * n)(*[t.shape[0] for t in tables])
+    ds = (C.c_int * n)(*[t.shape[1] for t in tables])
+    check(lib.mgx_sample_gather_embed(sp, i64, L, _dev_pos(pos, seq), n, tp, Vs, ds, B, R, _p(out), _stream()),
+          "mgx_sample_gather_embed")
+    return out
+
+
+def sample_head(h, gamma, beta, eps, w, bias, sizes, keys, pos=None, stochastic=False, seed=0, logits=None):
+    """Final Norm + the stacked output heads (class counts `sizes`) of row R-1 of h [B,R,d] bf16; keys [B, n] (int64
+    storage of the kernel's uint64 keys, zero on entry) receive per head the running argmax, or - stochastic - a
+    Gumbel-max draw from softmax(logits) keyed by (seed, *pos, b, class)."""
+    import ctypes as C
+    _need(h, "h", torch.bfloat16)
+    _need(w, "w", torch.bfloat16)
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (bias, "bias")):
+        _need(t, nm, torch.float32)
+    _need(keys, "keys", torch.int64)
+    B, R, d = h.shape
+    n, V = len(sizes), sum(sizes)
+    if w.shape != (V, d) or bias.numel() != V or gamma.numel() != d or beta.numel() != d or keys.numel() != B * n:
+        raise ValueError("sample_head: shape mismatch")
+    if logits is not None:
+        _need(logits, "logits", torch.float32)
+        if tuple(logits.shape) != (B, V):
+            raise ValueError("sample_head: logits must be [B, V]")
+    if stochastic and pos is None:
+        raise ValueError("sample_head: a stochastic draw needs the device-side position (its counter)")
+    Vs = (C.c_int * n)(*[int(v) for v in sizes])
+    check(lib.mgx_sample_head(_p(h), B, R, d, _p(gamma), _p(beta), eps, _p(w), _p(bias), n, Vs, int(bool(stochastic)),
+                              int(seed) & (2 ** 64 - 1), None if pos is None else _p(pos), _p(keys),
+                              None if logits is None else _p(logits), _stream()), "mgx_sample_head")
+
+
+def sample_commit(seq, pos, keys):
+    """seq[:, (k,) pos+1] = class held in keys[b, k]; keys = 0; pos += 1 (mgx_sample_commit)."""
+    sp, i64, L, B, n = _streams_args(seq)
+    _need(keys, "keys", torch.int64)
+    if keys.numel() != B * n:
+        raise ValueError("sample_commit: keys must hold one entry per sequence and stream")
+    check(lib.mgx_sample_commit(sp, i64, L, B, n, _dev_pos(pos, seq), _p(keys), _stream()), "mgx_sample_commit")
+
+
 def decode_gather_embed(seq, pos, table, R=3):
     """bf16 embedding rows of seq[:, pos .. pos+R-1] (mgx_decode_gather_embed); pos: one int32 on the device."""
     sp, i64, L = _seq_args(seq)

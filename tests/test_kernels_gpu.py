@@ -696,6 +696,93 @@ def test_decode_sampling_tail(B, d, V, seq_dtype):
     assert torch.equal(seq[:, pos0 + 2].long().cpu(), torch.full((B,), 3))
 
 
+@pytest.mark.parametrize("seq_dtype", [torch.int32, torch.int64])
+def test_sampling_tail_three_streams(seq_dtype):
+    """mgx_sample_gather_embed / _head / _commit with the separated model's three token streams
+    (inference_separated.py:18-28): three gathers + cat + cast (bit-exact), Norm + the three stacked heads (bf16
+    tolerance), one argmax per head over that head's classes only (exact on the kernel's logits), scatter into
+    seq[b, k, pos+1] (exact)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    B, L, R, pos0 = 9, 41, 3, 17
+    sizes, dims = (92, 130, 203), (256, 256, 512)
+    d = sum(dims)
+    seq = torch.stack([torch.randint(0, v, (B, L), generator=g) for v in sizes], 1).to(seq_dtype).cuda()
+    tables = [torch.randn(v, dk, generator=g).cuda() for v, dk in zip(sizes, dims)]
+    pos = torch.tensor([pos0], dtype=torch.int32).cuda()
+    emb = ops.sample_gather_embed(seq, pos, tables, R)
+    want = torch.cat([torch.nn.functional.embedding(seq[:, k, pos0:pos0 + R].long(), t) for k, t in enumerate(tables)],
+                     -1).to(torch.bfloat16)
+    assert torch.equal(emb.view(torch.int16), want.view(torch.int16))
+    h = (torch.randn(B, R, d, generator=g) * 2).bfloat16().cuda()
+    gamma, beta = (1 + 0.1 * torch.randn(d, generator=g)).cuda(), (0.1 * torch.randn(d, generator=g)).cuda()
+    V = sum(sizes)
+    w = (torch.randn(V, d, generator=g) / d ** 0.5).bfloat16().cuda()
+    bias = (0.1 * torch.randn(V, generator=g)).cuda()
+    keys = torch.zeros(B, 3, dtype=torch.int64).cuda()
+    logits = torch.empty(B, V, dtype=torch.float32).cuda()
+    ops.sample_head(h, gamma, beta, 1e-5, w, bias, sizes, keys, logits=logits)
+    y = torch.nn.functional.layer_norm(h[:, R - 1].float(), (d,), gamma, beta, 1e-5).bfloat16().float()
+    ref = (y @ w.float().t() + bias).bfloat16().float()
+    assert gu.rel_err(logits, ref) < BF16_TOL
+    before = seq.clone()
+    ops.sample_commit(seq, pos, keys)
+    torch.cuda.synchronize()
+    assert int(pos) == pos0 + 1 and int(keys.abs().sum()) == 0
+    off = 0
+    for k, v in enumerate(sizes):
+        assert torch.equal(seq[:, k, pos0 + 1].long(), torch.argmax(logits[:, off:off + v], -1)), k
+        off += v
+    keep = torch.ones(L, dtype=torch.bool)
+    keep[pos0 + 1] = False
+    assert torch.equal(seq[:, :, keep], before[:, :, keep])
+
+
+def test_sampling_stochastic_draw_follows_the_softmax():
+    """The stochastic branch (inference_unified.py:16-17: multinomial(softmax(logits), 1)) as a counter-based
+    Gumbel-max draw: over 64 identical sequences x 400 positions the class frequencies of each head match
+    softmax(that head's logits) (chi-square over the classes with >= 5 expected draws, 4.5 sigma), a re-run with the
+    same seed and positions reproduces every draw, another seed does not, and sequences / positions are independent
+    (not all equal)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    B, R, d = 64, 3, 256
+    sizes = (24, 40)
+    V = sum(sizes)
+    h = torch.randn(1, R, d, generator=g).bfloat16().expand(B, R, d).contiguous().cuda()
+    gamma, beta = torch.ones(d).cuda(), torch.zeros(d).cuda()
+    w = (2.0 * torch.randn(V, d, generator=g) / d ** 0.5).bfloat16().cuda()
+    bias = torch.zeros(V).cuda()
+    keys = torch.zeros(B, 2, dtype=torch.int64).cuda()
+    logits = torch.empty(B, V, dtype=torch.float32).cuda()
+    seq = torch.zeros(B, 2, 402, dtype=torch.int32).cuda()
+
+    def run(seed):
+        seq.zero_()
+        pos = torch.zeros(1, dtype=torch.int32).cuda()
+        for _ in range(400):
+            ops.sample_head(h, gamma, beta, 1e-5, w, bias, sizes, keys, pos=pos, stochastic=True, seed=seed, logits=logits)
+            ops.sample_commit(seq, pos, keys)
+        torch.cuda.synchronize()
+        return seq[:, :, 1:401].clone()
+
+    a = run(1234)
+    assert torch.equal(a, run(1234))
+    assert not torch.equal(a, run(99))
+    assert not torch.equal(a[0], a[1]) and not torch.equal(a[:, :, 0], a[:, :, 1])
+    off = 0
+    n = B * 400
+    for k, v in enumerate(sizes):
+        p = torch.softmax(logits[0, off:off + v].double(), -1).cpu()
+        cnt = torch.bincount(a[:, k].reshape(-1).long().cpu(), minlength=v).double()
+        assert int(cnt.sum()) == n and cnt.numel() == v
+        big = p * n >= 5
+        chi2 = float((((cnt - p * n) ** 2) / (p * n))[big].sum())
+        dof = int(big.sum()) - 1
+        assert dof >= 5 and chi2 < dof + 4.5 * (2 * dof) ** 0.5, (k, chi2, dof)
+        off += v
+
+
 @pytest.mark.parametrize("T,n", [(32768, 3072), (1000, 1544), (5, 8), (129, 512), (4097, 520)])
 def test_colsum(T, n):
     """mgx_colsum_bf16 against an fp64 column sum of the same bf16 values; run twice for bitwise reproducibility."""

@@ -392,6 +392,47 @@ def test_graphed_decode_equals_eager(dtype):
     assert int(c.max()) < 618 and torch.equal(c[:, -1], seq[:, -1]) and torch.equal(c[:, :8], seq[:, :8])
 
 
+@pytest.mark.parametrize("deterministic", [True, False])
+def test_graphed_decode_separated_bf16(deterministic):
+    """The separated model (inference_separated.py:18-28) on the fused sampling head/tail, bf16, at a kernel-shaped
+    width (d = 256 + 256 + 512): the HIP-graph replay writes exactly the tokens of the same kernels launched one by
+    one - greedy, and stochastic with the same generator state (counter-based draw) - tokens stay inside each
+    stream's vocabulary, primer and last column are untouched; greedy also equals the unfused step (rows() + argmax)
+    wherever the two top logits of the fused step are not within bf16 rounding of each other."""
+    from musicgeneration_amd.model_baseline.alibi_separated import AlibiTransformer
+    from musicgeneration_amd.decode import KVCacheDecoder, sample_next_plus_one
+    torch.manual_seed(5)
+    m = AlibiTransformer(92, 130, 203, 256, 256, 512, 2, 8, 128, 1024, dropout=0.0, dtype="bf16").cuda().eval()
+    B, L = 4, 72
+    g = torch.Generator().manual_seed(6)
+    seq = torch.zeros(B, 3, L, dtype=torch.int32).cuda()
+    seq[:, :, 1:9] = torch.stack([torch.randint(2, v - 1, (B, 8), generator=g) for v in (92, 130, 203)], 1).cuda().int()
+    assert KVCacheDecoder(m, B, L).fused_step_supported(seq)
+    torch.manual_seed(11)
+    a = sample_next_plus_one(m, seq.clone(), idx=9, deterministic=deterministic, use_graph=True)
+    torch.manual_seed(11)
+    b = sample_next_plus_one(m, seq.clone(), idx=9, deterministic=deterministic, use_graph=False)
+    assert torch.equal(a, b)
+    for k, v in enumerate((92, 130, 203)):
+        assert int(a[:, k].max()) < v and int(a[:, k].min()) >= 0
+    assert torch.equal(a[:, :, :9], seq[:, :, :9]) and torch.equal(a[:, :, -1], seq[:, :, -1])
+    assert int((a[:, :, 9:L - 1] != 0).sum()) > 0
+    if not deterministic:
+        torch.manual_seed(12)
+        c = sample_next_plus_one(m, seq.clone(), idx=9, deterministic=False, use_graph=True)
+        assert not torch.equal(a, c)                            # another seed, another continuation
+        return
+    # the unfused step on the same prefix: its argmax agrees unless the decision is inside bf16 rounding
+    dec = KVCacheDecoder(m, B, L)
+    i = 30
+    dec.rows(a[:, :, :i - 1], 0)
+    heads = dec.rows(torch.cat([a[:, :, i - 1:i], seq[:, :, i:i + 2]], 2), i - 1)    # rows i, i+1 still stale (zeros)
+    for k, hk in enumerate(heads):
+        top2 = hk[:, 2].float().topk(2, -1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 0.05 * top2[:, 0].abs().clamp_min(1.0)
+        assert torch.equal(hk[:, 2].float().argmax(-1)[clear], a[:, k, i].long()[clear]), k
+
+
 def test_training_loop_end_to_end(tmp_path):
     """training_loop with the reference's signature: loss decreases on a repeating batch,
     checkpoints carry the reference's keys ('optmizer', 'grad_scaler', model 'mask') and resume."""
