@@ -303,6 +303,17 @@ int mgx_gemm_tn_pair_bf16(const void* A0, const void* B0, void* C0, int M0, int 
                           const void* A1, const void* B1, void* C1, int M1, int N1, int lda1, int ldb1, int K,
                           float* workspace, int out_dtype, void* stream);
 
+/* ---- generic GEMM: the fp32 parity mode and every shape off the tuned kernels' grid ---------------------------
+ * C[M,N] = opA(A)[M,K] . opB(B)[K,N] (+ bias[N] fp32) (+ res[M,N]); transA: A is stored [K,M]; transB: B is stored
+ * [N,K] (nn.Linear's weight, alibi_unified.py:90,92,137; Conv1d's [in,out] weight, base_layers.py:54-57, is transB = 0).
+ * Replaces torch.addmm / mm / F.linear wherever mgx_gemm_nt/tn/skinny do not apply: fp32 storage (north_star's 1e-5
+ * mode), bf16 widths that are not multiples of 64, unpadded vocabularies.  Any sizes, any row strides (lda/ldb/ldc/ldr
+ * in elements), a/b/c/res each MGX_F32 or MGX_BF16; products and sums in fp32 (v_mfma_f32_32x32x2_f32), K walked in
+ * order in one launch (deterministic).  res may alias C.  A correctness path, not a tuned one. */
+int mgx_gemm_generic(const void* A, const void* B, void* C, const float* bias, const void* res, int M, int N, int K,
+                     int lda, int ldb, int ldc, int ldr, int transA, int transB, int a_dtype, int b_dtype, int c_dtype,
+                     int res_dtype, void* stream);
+
 /* ---- decode-time projections (M <= 256 token rows) --------------------------------------------------
  * out[M,N] (bf16) = epilogue(A[M,K] . Wt[N,K]^T + bias[N]); A, Wt, res, out bf16 row-major; bias / gamma / beta fp32.
  * Replaces, for the three token rows per sequence of a sampling step (inference_unified.py:15), Conv1d.forward /

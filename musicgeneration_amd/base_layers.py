@@ -282,10 +282,8 @@ class Conv1d(nn.Module):
         self.b = nn.Parameter(torch.zeros([nf]))
 
     def forward(self, x):
-        lead = x.shape[:-1]
-        w = self.w.view(self.nx, self.nf).to(x.dtype)
-        y = torch.addmm(self.b.to(x.dtype), x.reshape(-1, self.nx), w)
-        return y.view(*lead, self.nf)
+        w = self.w.view(self.nx, self.nf)
+        return ops.linear(x, w if w.dtype == x.dtype else w.to(x.dtype), self.b, w_is_nk=False)   # mgx_gemm_generic
 
 
 class Attention(nn.Module):
@@ -343,4 +341,4 @@ def tied_head(h, table, shadow: ShadowCache):
         logits.mgx_padded_base = padded
         return logits
     emb = table if h.dtype == torch.float32 else table.to(h.dtype)
-    return (h.reshape(-1, h.shape[-1]) @ emb.t()).reshape(*h.shape[:-1], V)
+    return ops.linear(h, emb)                                  # fp32 / odd widths: mgx_gemm_generic

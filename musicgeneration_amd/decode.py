@@ -98,8 +98,12 @@ class KVCacheDecoder:
                 h2 = ops.skinny_gemm(hact, W.w2, W.m_b2, ws, res=h1, gamma=W.m_g2, beta=W.m_be2, eps=layer.norm2.eps)
                 h = h2.view(B, R, d)
                 continue
-            wqkv, bqkv, wp, bp, w1, w2, b2 = W.wqkv, W.bqkv, W.wp, W.bp, W.w1, W.w2, W.b2
-            qkv = torch.addmm(bqkv, x2, wqkv).view(B, R, 3 * d)
+            # fp32 (parity mode), prefill (R > 4) and widths off the skinny kernel's grid: the tuned NT GEMM where it
+            # applies (bf16, K a multiple of 64), the generic libmgx GEMM otherwise
+            nt = dt == torch.bfloat16 and d % 64 == 0 and ff % 64 == 0
+            proj = (lambda xx, w_kn, w_nk, b: ops.gemm_nt(xx, w_nk(), b)) if nt else \
+                (lambda xx, w_kn, w_nk, b: ops.gemm(xx, w_kn(), bias=b))
+            qkv = proj(x2, lambda: W.wqkv, lambda: W.wqkv_t, W.m_bqkv).view(B, R, 3 * d)
             if R <= 4 and ops.decode_step_attn_supported(dt, d // layer.heads):
                 a = ops.decode_step_attn(qkv, kc, vc, layer.attn.slopes, pos0)      # append + attend, one launch
             else:
@@ -109,11 +113,11 @@ class KVCacheDecoder:
                     a = ops.decode_attn(q, kc, vc, layer.attn.slopes, pos0)
                 else:
                     a, _ = ops.alibi_attn_fwd(qkv, layer.attn.slopes, layer.heads)
-            pr = torch.addmm(bp, a.view(T, d), wp)
+            pr = proj(a.view(T, d), lambda: W.wp, lambda: W.wp_t, W.m_bp)
             h1, _, _, _ = ops.ln_residual_fwd(pr, x2, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps, save=False)
-            u = torch.mm(h1, w1.t())
+            u = ops.gemm_nt(h1, W.w1) if nt else ops.gemm(h1, W.w1, trans_b=True)
             _, hact = ops.bias_act_fwd(u, layer.linear1.bias, layer.activation)
-            v = torch.addmm(b2, hact, w2.t())
+            v = ops.gemm_nt(hact, W.w2, W.m_b2) if nt else ops.gemm(hact, W.w2, trans_b=True, bias=W.m_b2)
             h2, _, _, _ = ops.ln_residual_fwd(v, h1, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps, save=False)
             h = h2.view(B, R, d)
         return h

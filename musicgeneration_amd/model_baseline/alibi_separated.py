@@ -96,7 +96,7 @@ class AlibiTransformer(nn.Module):
             packed = ops.padded_head(h, w_pad, w_pad_t, b_pad, (ws[0], bs[0], ws[1], bs[1], ws[2], bs[2]))
             return SeparatedLogits(packed, sizes)
         w, b = wb if wb is not None else self.head_weights(h.dtype)
-        return SeparatedLogits(F.linear(h, w, b), sizes)
+        return SeparatedLogits(ops.linear(h, w, b), sizes)     # fp32 / odd widths: mgx_gemm_generic
 
     def forward(self, x: torch.Tensor):
         if x.dim() != 3 or x.shape[1] != 3:

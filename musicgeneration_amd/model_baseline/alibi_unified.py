@@ -166,7 +166,7 @@ class AlibiTransformer(nn.Module):
             logits.mgx_padded_base = padded          # explicit carrier for Criterion (no copy, padded gradient)
             return logits
         w, b = wb if wb is not None else self.head_weights(h.dtype)
-        return F.linear(h, w, b)
+        return ops.linear(h, w, b)                             # fp32 / odd widths: mgx_gemm_generic
 
     def forward(self, x: torch.Tensor):
         """x [B,S] int32/int64 -> logits [B,S,vocab] in the compute dtype (alibi_unified.py:124-138)."""

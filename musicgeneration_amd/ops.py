@@ -357,6 +357,83 @@ def gemm_tn_pair(a0, b0, a1, b1, out0=None, out1=None, tag="gemm_tn"):
     return c0, c1
 
 
+def _mat(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"gemm: {name}: musicgeneration_amd runs on the GPU only (tensor is on {t.device}); "
+                           "there is no CPU fallback")
+    if t.dim() != 2 or t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"gemm: {name} must be a 2-D fp32 / bf16 tensor")
+    return t if t.stride(1) == 1 and t.stride(0) >= t.shape[1] else t.contiguous()
+
+
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, res=None, out_dtype=None, out=None):
+    """C = op(a) @ op(b) (+ bias) (+ res) on mgx_gemm_generic: the fp32 parity mode and every shape the tuned bf16
+    kernels do not take (any sizes and row strides; fp32 accumulation on the fp32 MFMA; deterministic).
+    trans_a: a is stored [K, M]; trans_b: b is stored [N, K].  bias fp32 [N]; res [M, N] may be `out` (in place)."""
+    a, b = _mat(a, "a"), _mat(b, "b")
+    K, M = a.shape if trans_a else a.shape[::-1]
+    N, Kb = b.shape if trans_b else b.shape[::-1]
+    if K != Kb:
+        raise ValueError(f"gemm: inner dimensions differ ({K} and {Kb})")
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype or a.dtype, device=a.device)
+    elif out.shape != (M, N) or out.stride(1) != 1 or not out.is_cuda or out.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("gemm: out must be an [M, N] fp32 / bf16 GPU tensor with unit column stride")
+    if bias is not None:
+        if bias.dtype != torch.float32:
+            bias = bias.float()
+        _need(bias, "bias", torch.float32)
+        if bias.numel() != N:
+            raise ValueError("gemm: bias length")
+    if res is not None:
+        res = res if res is out else _mat(res, "res")
+        if res.shape != (M, N):
+            raise ValueError("gemm: res shape")
+    if M == 0 or N == 0:
+        return out
+    if K == 0:
+        raise ValueError("gemm: empty inner dimension")
+    dt = lambda t: _lib.BF16 if t.dtype == torch.bfloat16 else _lib.F32
+    check(lib.mgx_gemm_generic(a.data_ptr(), b.data_ptr(), out.data_ptr(), None if bias is None else _p(bias),
+                               None if res is None else res.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+                               0 if res is None else res.stride(0), int(trans_a), int(trans_b), dt(a), dt(b), dt(out),
+                               dt(out) if res is None else dt(res), _stream()), "mgx_gemm_generic")
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    """y = x @ W (+ b) with W stored [K, N] (Conv1d, base_layers.py:54-57) or [N, K] (nn.Linear / a tied embedding
+    table: alibi_unified.py:137, relative_transformer.py:116-119) on ops.gemm; the three GEMMs of its backward too."""
+
+    @staticmethod
+    def forward(ctx, x2, w, bias, w_is_nk):
+        ctx.save_for_backward(x2, w)
+        ctx.w_is_nk = w_is_nk
+        ctx.has_bias = bias is not None
+        return gemm(x2, w, trans_b=w_is_nk, bias=bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy = _mat(dy, "dy")
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(dy, w, trans_b=not ctx.w_is_nk, out_dtype=x2.dtype)
+        if ctx.needs_input_grad[1]:
+            dw = gemm(dy, x2, trans_a=True, out_dtype=w.dtype) if ctx.w_is_nk else gemm(x2, dy, trans_a=True, out_dtype=w.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0, dtype=torch.float32)
+        return dx, dw, db, None
+
+
+def linear(x, w, bias=None, w_is_nk=True):
+    """x [..., K] -> [..., N]: F.linear (w [N, K]) or Conv1d's x @ w + b (w [K, N], w_is_nk=False), differentiable,
+    on the generic libmgx GEMM.  bias fp32 (or any float dtype: read as fp32)."""
+    lead = x.shape[:-1]
+    y = _Linear.apply(x.reshape(-1, x.shape[-1]), w, None if bias is None else bias.float(), w_is_nk)
+    return y.view(*lead, y.shape[-1])
+
+
 def grad_slot(master, shape):
     """Where a weight gradient should be written: the parameter's slot of its data-parallel gradient bucket
     (data_parallel.GradientBucketer tags every parameter with `mgx_grad_slot`), viewed as `shape`, when the parameter has
@@ -659,9 +736,9 @@ def padded_head(h, w_pad, w_pad_t, b_pad, masters):
 # whole post-LN decoder block as one autograd node
 # ---------------------------------------------------------------------------
 def _mfma_gemms(x2, d, ff):
-    """bf16 blocks whose widths the MFMA GEMMs take (K a multiple of 64 at every projection site) run all twelve
-    GEMMs of the block (four forward, four dgrad, four weight gradients) on libmgx; fp32 (the 1e-5 parity mode) and
-    odd widths use plain library GEMMs."""
+    """bf16 blocks whose widths the tuned MFMA GEMMs take (K a multiple of 64 at every projection site) run all twelve
+    GEMMs of the block (four forward, four dgrad, four weight gradients) on gemm_nt / gemm_tn; fp32 (the 1e-5 parity
+    mode) and odd widths run the same twelve on the generic libmgx GEMM (ops.gemm)."""
     return x2.dtype == torch.bfloat16 and d % 64 == 0 and ff % 64 == 0
 
 
@@ -690,7 +767,7 @@ class _DecoderBlock(torch.autograd.Function):
         if mfma:
             qkv = gemm_nt(x2, W.wqkv_t, W.m_bqkv).view(B, S, 3 * d)
         else:
-            qkv = torch.addmm(W.bqkv, x2, W.wqkv).view(B, S, 3 * d)
+            qkv = gemm(x2, W.wqkv, bias=W.m_bqkv).view(B, S, 3 * d)
         if rope is not None:                      # rotary variant: rotate q | k in place, then plain causal attention
             rope_qk_(qkv, rope[0], rope[1], n_heads)
         if E is None:
@@ -698,7 +775,7 @@ class _DecoderBlock(torch.autograd.Function):
         else:
             a, lse = rel_attn_fwd(qkv, E, n_heads)
         a2 = a.view(T, d)
-        pr = gemm_nt(a2, W.wp_t, W.m_bp) if mfma else torch.addmm(W.bp, a2, W.wp)
+        pr = gemm_nt(a2, W.wp_t, W.m_bp) if mfma else gemm(a2, W.wp, bias=W.m_bp)
         h1, z1, mean1, rstd1 = ln_residual_fwd(pr, x2, W.m_g1, W.m_be1, eps, p, seed1)
         if mfma:
             # bias + activation + dropout in the up-projection's epilogue (two outputs: the activated tensor for
@@ -707,9 +784,9 @@ class _DecoderBlock(torch.autograd.Function):
             pre, hact = gemm_nt(h1, W.w1, W.m_b1, act=act, p_drop=p, seed=seed2)
             v = gemm_nt(hact, W.w2, W.m_b2)
         else:
-            u = torch.mm(h1, W.w1_t)
+            u = gemm(h1, W.w1, trans_b=True)
             pre, hact = bias_act_fwd(u, W.m_b1, act, p, seed2)
-            v = torch.addmm(W.b2, hact, W.w2_t)
+            v = gemm(hact, W.w2, trans_b=True, bias=W.m_b2)
         h2, z2, mean2, rstd2 = ln_residual_fwd(v, h1, W.m_g2, W.m_be2, eps)
         ctx.save_for_backward(x2, qkv, a, lse, z1, mean1, rstd1, h1, pre, hact, z2, mean2, rstd2, slopes, E)
         ctx.W = W
@@ -732,17 +809,17 @@ class _DecoderBlock(torch.autograd.Function):
                                     grad_slot(W.m_w1, (dpre.shape[1], d)))
             dh1 = gemm_nt(dpre, W.w1_t)                                                 # [T, d]
         else:
-            dw2 = torch.mm(dz2.t(), hact)
-            dpre, db1 = bias_act_bwd(torch.mm(dz2, W.w2), pre, act, p, seed2)
-            dw1 = torch.mm(dpre.t(), h1)
-            dh1 = torch.mm(dpre, W.w1)
+            dw2 = gemm(dz2, hact, trans_a=True, out_dtype=f32)
+            dpre, db1 = bias_act_bwd(gemm(dz2, W.w2), pre, act, p, seed2)
+            dw1 = gemm(dpre, h1, trans_a=True, out_dtype=f32)
+            dh1 = gemm(dpre, W.w1)
         dz1, da1, dg1, dbe1, dbp = ln_residual_bwd(dh1, dz2, z1, mean1, rstd1, W.m_g1, p, seed1, want_dsum=True)
         a2 = a.view(T, d)
         if mfma:
             da = gemm_nt(da1, W.wp).view(B, S, d)                                       # da1 @ wp^T
         else:
-            dwp = torch.mm(a2.t(), da1)
-            da = torch.mm(da1, W.wp_t).view(B, S, d)
+            dwp = gemm(a2, da1, trans_a=True, out_dtype=f32)
+            da = gemm(da1, W.wp, trans_b=True).view(B, S, d)
         if E is None:
             dqkv = alibi_attn_bwd(da, qkv, a, lse, slopes, n_heads)
             dE = None
@@ -757,10 +834,9 @@ class _DecoderBlock(torch.autograd.Function):
             dwp, dwqkv = gemm_tn_pair(a2, da1, x2, dqkv2, grad_slot(W.m_wp, (d, d)), grad_slot(W.m_wqkv, (d, 3 * d)))
             dx = gemm_nt(dqkv2, W.wqkv, None, dz1).view(B, S, d)                        # dqkv @ wqkv^T + dz1
         else:
-            dwqkv = torch.mm(x2.t(), dqkv2)
-            # in place: out-of-place addmm first copies dz1 into its result.  dz1 (and da1, which aliases it
-            # without dropout) has no reader after this point
-            dx = dz1.addmm_(dqkv2, W.wqkv_t).view(B, S, d)
+            dwqkv = gemm(x2, dqkv2, trans_a=True, out_dtype=f32)
+            # in place (res aliases out).  dz1 (and da1, which aliases it without dropout) has no reader after this point
+            dx = gemm(dqkv2, W.wqkv, trans_b=True, res=dz1, out=dz1).view(B, S, d)
         return (dx, None, None, dE, None, None,
                 dwqkv.unsqueeze(0), dbqkv, dwp.unsqueeze(0), dbp, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2)
 

@@ -214,8 +214,8 @@ def _gemm_backward(ctx, dc):
     dc = dc.contiguous()
     K = a.shape[1]
     # da = dc @ bt needs bt^T as the [K, N] "Bt" operand; dbt = dc^T @ a on the TN kernel
-    da = torch.ops.mgx.gemm_nt(dc, bt.t().contiguous(), None) if dc.shape[1] % 64 == 0 and K % 8 == 0 else dc @ bt
-    dbt = torch.ops.mgx.gemm_tn(dc, a).to(bt.dtype) if dc.shape[1] % 8 == 0 and K % 8 == 0 else (dc.t() @ a)
+    da = torch.ops.mgx.gemm_nt(dc, bt.t().contiguous(), None) if dc.shape[1] % 64 == 0 and K % 8 == 0 else ops.gemm(dc, bt)
+    dbt = torch.ops.mgx.gemm_tn(dc, a).to(bt.dtype) if dc.shape[1] % 8 == 0 and K % 8 == 0 else ops.gemm(dc, a, trans_a=True)
     dbias = torch.ops.mgx.colsum(dc) if ctx.has_bias else None
     return da, dbt, dbias
 

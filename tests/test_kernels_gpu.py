@@ -783,6 +783,57 @@ def test_sampling_stochastic_draw_follows_the_softmax():
         off += v
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 7, 3), (130, 129, 17), (192, 618, 96), (257, 96, 1024), (1000, 425, 333)])
+@pytest.mark.parametrize("trans_a,trans_b", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_generic(M, N, K, trans_a, trans_b):
+    """mgx_gemm_generic (the fp32 parity mode's GEMM and the one for shapes off the tuned kernels' grid) against an
+    fp64 product of the same values: fp32 storage to 2e-6, bf16 storage to the rounding of its output; both operand
+    orientations, odd sizes, a strided operand, bias, an aliased residual, mixed input / output dtypes; bit-identical
+    on a re-run."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn((K, M) if trans_a else (M, K), generator=g).cuda()
+    wide = torch.randn((N, K + 5) if trans_b else (K, N + 5), generator=g).cuda()
+    b = wide[:, :K] if trans_b else wide[:, :N]                  # row stride > width
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    A = (a.t() if trans_a else a).double()
+    Bm = (b.t() if trans_b else b).double()
+    want = A @ Bm + bias.double() + res.double()
+    got = ops.gemm(a, b, trans_a, trans_b, bias=bias, res=res)
+    assert got.dtype == torch.float32 and gu.rel_err(got, want) < 2e-6
+    assert torch.equal(got, ops.gemm(a, b, trans_a, trans_b, bias=bias, res=res))
+    inplace = res.clone()
+    ops.gemm(a, b, trans_a, trans_b, bias=bias, res=inplace, out=inplace)
+    assert torch.equal(inplace, got)
+    ab, bb = a.bfloat16(), b.bfloat16()
+    wantb = (ab.t() if trans_a else ab).double() @ (bb.t() if trans_b else bb).double()
+    gotb = ops.gemm(ab, bb, trans_a, trans_b)
+    assert gotb.dtype == torch.bfloat16 and gu.rel_err(gotb, wantb) < 4e-3
+    got32 = ops.gemm(ab, bb, trans_a, trans_b, out_dtype=torch.float32)      # bf16 in, fp32 out: a weight gradient
+    assert gu.rel_err(got32, wantb) < 2e-6
+
+
+def test_linear_autograd_on_the_generic_gemm():
+    """ops.linear (F.linear / Conv1d's x @ w + b on mgx_gemm_generic): output and the three gradients against torch's
+    own fp64 autograd, both weight orientations."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    for nk in (True, False):
+        x = torch.randn(3, 37, 96, generator=g).cuda().requires_grad_(True)
+        w = torch.randn((50, 96) if nk else (96, 50), generator=g).cuda().requires_grad_(True)
+        bvec = torch.randn(50, generator=g).cuda().requires_grad_(True)
+        y = ops.linear(x, w, bvec, w_is_nk=nk)
+        dy = torch.randn(y.shape, generator=g).cuda()
+        y.backward(dy)
+        xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, bvec))
+        yd = xd @ (wd.t() if nk else wd) + bd
+        yd.backward(dy.double())
+        assert gu.rel_err(y, yd) < 2e-6
+        for got, want in ((x.grad, xd.grad), (w.grad, wd.grad), (bvec.grad, bd.grad)):
+            assert gu.rel_err(got, want) < 2e-6
+
+
 @pytest.mark.parametrize("T,n", [(32768, 3072), (1000, 1544), (5, 8), (129, 512), (4097, 520)])
 def test_colsum(T, n):
     """mgx_colsum_bf16 against an fp64 column sum of the same bf16 values; run twice for bitwise reproducibility."""
