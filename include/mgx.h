@@ -268,15 +268,19 @@ int mgx_cast_shadow_bf16(int count, const float* const* src, void* const* dst, v
  * NT: C[M,N] = A[M,K] . Bt[N,K]^T (+ bias[N] fp32) (+ res[M,N] bf16); all bf16, K % 64 == 0, N % 8 == 0,
  *     lda/ldb/ldc multiples of 8.  act = -1: nothing more.  act = MGX_ACT_*: with pre = the bf16-rounded
  *     A.Bt^T + bias, C2[M,N] = dropout(act(pre)) (alibi_unified.py:90-91; dropout keyed by (seed, m*N+n), the same
- *     mask mgx_bias_act_bwd regenerates) and C[M,N] = act'(pre) * mask/(1-p), the derivative factor the backward
- *     multiplies by (mgx_gemm_nt_dfac_bf16); the pre-activation itself is not stored.  res must be NULL then.
+ *     mask mgx_bias_act_bwd regenerates) and C = the derivative factor act'(pre) * mask the backward multiplies by
+ *     (mgx_gemm_nt_dfac_bf16) as ONE BYTE per element: C is then an [M,N] uint8 matrix with a row stride of ldc BYTES,
+ *     value = (code - 27) * step, step = 0x1.47aep-8 with its low 8 mantissa bits cleared (~0.005: GELU' in
+ *     [-0.129, 1.129] to +-0.0025) or 2^-7 for ReLU (0 / 1 exact); code 27 = a dropped element = exactly 0.  The
+ *     pre-activation itself is not stored.  res must be NULL then.
  */
 int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2, const float* bias, const void* res,
                      int M, int N, int K, int lda, int ldb, int ldc, int act, float p_drop,
                      unsigned long long seed, void* stream);
 /* NT with the backward of `drop(activation(.))` (alibi_unified.py:90-91) as its epilogue: the dgrad GEMM of
  * linear2 (autograd of alibi_unified.py:92) times the derivative factor the forward left, in one launch:
- *   C[M,N] = (A[M,K] . Bt[N,K]^T) * fac[M,N]      fac [M,N] bf16 (ld = ldc) = C of mgx_gemm_nt_bf16 with act >= 0;
+ *   C[M,N] = (A[M,K] . Bt[N,K]^T) * fac[M,N] / (1 - p_drop)      fac [M,N] uint8 codes (row stride ldc bytes) = C of
+ *   mgx_gemm_nt_bf16 with the same act >= 0 and p_drop;
  *   colpart [mgx_gemm_nt_dfac_colpart_rows(M,N), N] fp32 (may be NULL) = partial column sums of the rounded C, two
  *   rows per row tile (one per wave row; the row tile is 256 rows, or 128 where 256-row tiles would leave a quarter
  *   of the chip idle - which is why the row count is a function and not a formula): their sum over rows is the bias
@@ -286,7 +290,7 @@ int mgx_gemm_nt_bf16(const void* A, const void* Bt, void* C, void* C2, const flo
 int mgx_gemm_nt_dfac_colpart_rows(int M, int N);
 long mgx_gemm_nt_dfac_colpart_floats(int M, int N);
 int mgx_gemm_nt_dfac_bf16(const void* A, const void* Bt, const void* fac, void* C, float* colpart, float* dbias, int M,
-                          int N, int K, int lda, int ldb, int ldc, void* stream);
+                          int N, int K, int lda, int ldb, int ldc, int act, float p_drop, void* stream);
 /* TN (weight gradients): C[M,N] = A[K,M]^T . B[K,N], bf16 inputs, split over K into fp32 slabs in
  * `workspace` (mgx_gemm_tn_workspace_floats() floats) and reduced in a fixed order (deterministic);
  * C is fp32 or bf16 (out_dtype).  M, N, lda, ldb multiples of 8. */

@@ -65,7 +65,7 @@ PROTOTYPES = {
     "mgx_gemm_nt_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _vp]),
     "mgx_gemm_nt_dfac_colpart_floats": (_l, [_i, _i]),
     "mgx_gemm_nt_dfac_colpart_rows": (_i, [_i, _i]),
-    "mgx_gemm_nt_dfac_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mgx_gemm_nt_dfac_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "mgx_gemm_generic": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mgx_gemm_tn_workspace_floats": (_l, [_i, _i, _i, _vp]),
     "mgx_gemm_tn_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

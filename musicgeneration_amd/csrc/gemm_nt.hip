@@ -1,8 +1,9 @@
 // bf16 MFMA GEMM, NT form, for the projections of the decoder block (gfx950):
 //   C[M,N] = A[M,K] . Bt[N,K]^T  (+ bias[N]) (+ residual[M,N]) (-> activation / activation backward)
-// The activation epilogue writes dropout(act(pre)) and, for the backward, the derivative factor
-// fac = act'(pre) * mask / (1 - p) in bf16; the activation-backward dgrad is then (A . Bt^T) * fac: one multiply per
-// element instead of erf + exp + the dropout hash (the epilogue is serial with the main loop on a CU).
+// The activation epilogue writes dropout(act(pre)) and, for the backward, the derivative factor act'(pre) * mask as ONE
+// BYTE per element (a uniform code, see FacCode); the activation-backward dgrad is then (A . Bt^T) * fac / (1 - p): a
+// byte conversion and two multiplies per element instead of erf + exp + the dropout hash (the epilogue is serial with
+// the main loop on a CU), and half the bytes of a bf16 side tensor in both directions.
 // Replaces Conv1d.forward (base_layers.py:54-57: reshape -> matmul -> +b), the nn.Linear calls of
 // DecoderBlock.forward (alibi_unified.py:90,92) and the dgrad GEMMs autograd derives from them.
 //
@@ -33,11 +34,11 @@ constexpr int LDS_B = 65536;                       // Bt half tiles start here; 
 struct NtArgs {
     const char* A;
     const char* B;
-    bf16_t* C;               // [M,N]
+    bf16_t* C;               // [M,N]; EPI_ACT: the derivative-factor codes, one BYTE per element, row stride ldc bytes
     bf16_t* C2;              // second output (EPI_ACT) or null
     const float* bias;       // [N] or null
     const bf16_t* res;       // [M,N] or null (EPI_PLAIN)
-    const bf16_t* fac;       // [M,N] derivative factor written by the EPI_ACT forward (EPI_DFAC)
+    const unsigned char* fac;  // [M,N] derivative-factor codes written by the EPI_ACT forward (EPI_DFAC)
     float* colpart;          // [gridM, N] per-row-tile column sums of C (EPI_DFAC) or null
     int M, N, K;
     int lda, ldb, ldc;
@@ -73,6 +74,24 @@ __device__ __forceinline__ void gelu_val_grad(float x, float& y, float& dy) {
     y = x * cdf;
     dy = fmaf(x * 0.3989422804014327f, e, cdf);
 }
+
+// Derivative factor as one byte: act'(pre) * mask = (code - ZERO) * STEP.  GELU' lies in [-0.1288, 1.1288]: STEP ~ 0.005
+// covers [-0.135, 1.139] with |error| <= 0.0025 (bf16 rounds a factor near 1 by up to 0.0039); its low 8 mantissa bits
+// are cleared, so code * STEP and ZERO * STEP are exact in fp32 and code ZERO (a dropped element) decodes to exactly
+// 0.  ReLU' is 0 or 1: STEP = 2^-7 makes both exact.  The 1 / (1 - p) of dropout is applied by the consumer.
+template <int ACT>
+struct FacCode {
+    static constexpr int ZERO = 27;
+    static constexpr float STEP = ACT == MGX_ACT_RELU ? 0.0078125f : __builtin_bit_cast(float, 0x3BA3D700u);
+    // four factors -> four codes in one dword: v_cvt_pk_u8_f32 rounds to nearest, saturates to [0, 255] and drops the
+    // byte into place (one fma + one conversion per element)
+    __device__ static __forceinline__ unsigned enc4(const float (&f)[4]) {
+        unsigned w = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(f[r], 1.0f / STEP, (float)ZERO), r, w);
+        return w;
+    }
+};
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
     union { bf16x2 v; unsigned u; } x;
@@ -255,9 +274,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
     // fragments have left, and one round trip is exposed per tile), 16 bytes per lane in the layout of the stores
     // below and turned back into the accumulator layout by the same 16-lane-row swap
     const bool has_side = EPI == EPI_DFAC || (EPI == EPI_PLAIN && g.res);
-    uint4 raw[2][2][4];
+    uint4 raw[2][2][4];                                 // EPI_DFAC uses .x / .y only: 8 codes per lane
     if (has_side) {
-        const bf16_t* sp = EPI == EPI_DFAC ? g.fac : g.res;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -266,9 +284,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
                 for (int i = 0; i < 4; ++i) {
                     const int nc = min(n0 + NT_COL0(wc, qb) + nsw, g.N - 8);
                     const int mc = min(m0 + 128 * qa + 64 * wr + 16 * i + l15, g.M - 1);
-                    raw[qb][qa][i] = *reinterpret_cast<const uint4*>(sp + (long)mc * g.ldc + nc);
+                    if (EPI == EPI_DFAC) {
+                        const uint2 t = *reinterpret_cast<const uint2*>(g.fac + (long)mc * g.ldc + nc);
+                        raw[qb][qa][i] = make_uint4(t.x, t.y, 0u, 0u);
+                    } else {
+                        raw[qb][qa][i] = *reinterpret_cast<const uint4*>(g.res + (long)mc * g.ldc + nc);
+                    }
                 }
     }
+    // EPI_DFAC: decode (code - ZERO) * STEP / (1 - p) as fma(code, fs, -ZERO * fs); ACT carries the code grid.  fs keeps
+    // 16 mantissa bits, so code * fs and ZERO * fs are exact and a dropped element (code ZERO) decodes to exactly 0
+    const float fs = __uint_as_float(__float_as_uint(FacCode<ACT>::STEP * keep_scale) & 0xFFFFFF00u);
+    const float fz = -(float)FacCode<ACT>::ZERO * fs;
     f32x4 bv[2][2];
     float csum[2][2][4];
 #pragma unroll
@@ -291,8 +318,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[j][r] = acc[qa][qb][i][j][r] + bv[qb][j][r];
-        if (has_side) {
-            // residual: C = v + res; derivative factor: C = v * fac (columns past N: some real value, never stored)
+        if (EPI == EPI_DFAC) {
+            // C = v * fac: the lane's 8 codes go back to the accumulator layout by the 16-lane-row swap of the stores
+            const uint4 rw = raw[qb][qa][i];
+            auto sw = __builtin_amdgcn_permlane16_swap(rw.x, rw.y, false, false);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[j][r] *= fmaf((float)((sw[j] >> (8 * r)) & 0xFFu), fs, fz);
+        } else if (has_side) {
+            // residual: C = v + res (columns past N: some real value, never stored)
             const uint4 rw = raw[qb][qa][i];
             auto s0 = __builtin_amdgcn_permlane16_swap(rw.x, rw.z, false, false);
             auto s1 = __builtin_amdgcn_permlane16_swap(rw.y, rw.w, false, false);
@@ -300,7 +336,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
             for (int j = 0; j < 2; ++j) {
                 const float x[4] = {bf_lo(s0[j]), bf_hi(s0[j]), bf_lo(s1[j]), bf_hi(s1[j])};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[j][r] = EPI == EPI_DFAC ? v[j][r] * x[r] : v[j][r] + x[r];
+                for (int r = 0; r < 4; ++r) v[j][r] += x[r];
             }
         }
         unsigned o[2][2], o2[2][2];
@@ -322,8 +358,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
             }
         }
         if (EPI == EPI_ACT) {
-            // o2 = dropout(act(pre)), o = act'(pre) * mask / (1 - p); both see the pre-activation rounded to bf16
-            // (the value an unfused pass would read back)
+            // o2 = dropout(act(pre)), o[j][0] = the four codes of act'(pre) * mask; both see the pre-activation rounded
+            // to bf16 (the value an unfused pass would read back)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = nb + 16 * j + 4 * g4;
@@ -344,11 +380,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
                     if (DROP) {
                         bool k0, k1;
                         mgx_keep_pair(g.seed, (unsigned long long)((long)mc * g.N + n + r), thr16, k0, k1);
-                        const float s0 = k0 ? keep_scale : 0.f, s1 = k1 ? keep_scale : 0.f;
-                        y0 *= s0;
-                        f0 *= s0;
-                        y1 *= s1;
-                        f1 *= s1;
+                        y0 *= k0 ? keep_scale : 0.f;
+                        f0 = k0 ? f0 : 0.f;
+                        y1 *= k1 ? keep_scale : 0.f;
+                        f1 = k1 ? f1 : 0.f;
                     }
                     y[r] = y0;
                     y[r + 1] = y1;
@@ -357,13 +392,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
                 }
                 o2[j][0] = pack2(y[0], y[1]);
                 o2[j][1] = pack2(y[2], y[3]);
-                o[j][0] = pack2(f[0], f[1]);
-                o[j][1] = pack2(f[2], f[3]);
+                o[j][0] = FacCode<ACT>::enc4(f);
             }
         }
         // 16-lane-row swap: odd rows of the j = 0 word <-> even rows of the j = 1 word
         const int n = nb + nsw;
-        {
+        if (EPI == EPI_ACT) {
+            auto sw = __builtin_amdgcn_permlane16_swap(o[0][0], o[1][0], false, false);
+            if (row_ok && n < g.N)
+                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(g.C) + (long)m * g.ldc + n) = make_uint2(sw[0], sw[1]);
+        } else {
             auto s0 = __builtin_amdgcn_permlane16_swap(o[0][0], o[1][0], false, false);
             auto s1 = __builtin_amdgcn_permlane16_swap(o[0][1], o[1][1], false, false);
             if (row_ok && n < g.N)
@@ -501,14 +539,17 @@ extern "C" int mgx_gemm_nt_dfac_colpart_rows(int M, int N) {
 extern "C" long mgx_gemm_nt_dfac_colpart_floats(int M, int N) { return (long)mgx_gemm_nt_dfac_colpart_rows(M, N) * N; }
 
 extern "C" int mgx_gemm_nt_dfac_bf16(const void* A, const void* Bt, const void* fac, void* C, float* colpart, float* dbias,
-                                     int M, int N, int K, int lda, int ldb, int ldc, void* stream) {
+                                     int M, int N, int K, int lda, int ldb, int ldc, int act, float p_drop, void* stream) {
     if (int rc = nt_check("mgx_gemm_nt_dfac_bf16", A, Bt, C, M, N, K, lda, ldb, ldc)) return rc;
     MGX_REQUIRE(fac, MGX_EINVAL, "mgx_gemm_nt_dfac_bf16: null derivative factor");
+    MGX_REQUIRE(act == MGX_ACT_GELU || act == MGX_ACT_RELU, MGX_EINVAL, "mgx_gemm_nt_dfac_bf16: bad act %d", act);
+    MGX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, MGX_EINVAL, "mgx_gemm_nt_dfac_bf16: p_drop=%f", p_drop);
     MGX_REQUIRE(!dbias || colpart, MGX_EINVAL, "mgx_gemm_nt_dfac_bf16: dbias needs the colpart workspace");
-    NtArgs g{(const char*)A, (const char*)Bt, (bf16_t*)C, nullptr, nullptr, nullptr, (const bf16_t*)fac, colpart,
-             M, N, K, lda, ldb, ldc, 0.f, 0ull};
+    NtArgs g{(const char*)A, (const char*)Bt, (bf16_t*)C, nullptr, nullptr, nullptr, (const unsigned char*)fac, colpart,
+             M, N, K, lda, ldb, ldc, p_drop, 0ull};
     const long nblk = nt_blocks(M, N);
-    NT_LAUNCH(EPI_DFAC, 0, false);
+    if (act == MGX_ACT_GELU) NT_LAUNCH(EPI_DFAC, MGX_ACT_GELU, false);
+    else NT_LAUNCH(EPI_DFAC, MGX_ACT_RELU, false);
     MGX_CHECK_LAUNCH("gemm_nt_dfac");
     if (dbias) {
         const int rows = mgx_gemm_nt_dfac_colpart_rows(M, N);

@@ -253,7 +253,8 @@ def bias_act_bwd(dh, pre, act="gelu", p_drop=0.0, seed=0):
 # ---------------------------------------------------------------------------
 def gemm_nt(a, bt, bias=None, res=None, act=None, p_drop=0.0, seed=0):
     """C = a[M,K] @ bt[N,K]^T (+ bias) (+ res); with act: returns (fac, dropout(act(pre))) where pre is the
-    bf16-rounded C and fac = act'(pre) * mask/(1-p) is what gemm_nt_dfac multiplies by in the backward."""
+    bf16-rounded C and fac [M,N] uint8 holds the codes of act'(pre) * mask that gemm_nt_dfac multiplies by in the
+    backward (one byte per element: include/mgx.h)."""
     _need(a, "a", torch.bfloat16)
     _need(bt, "bt", torch.bfloat16)
     M, K = a.shape
@@ -270,22 +271,33 @@ def gemm_nt(a, bt, bias=None, res=None, act=None, p_drop=0.0, seed=0):
         _need(res, "res", torch.bfloat16)
         if res.shape != (M, N):
             raise ValueError("gemm_nt: residual shape")
-    c = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
-    c2 = torch.empty_like(c) if act is not None else None
+    c = torch.empty(M, N, dtype=torch.bfloat16 if act is None else torch.uint8, device=a.device)
+    c2 = torch.empty(M, N, dtype=torch.bfloat16, device=a.device) if act is not None else None
     with _timed("gemm_nt", 2.0 * M * N * K):
         check(lib.mgx_gemm_nt_bf16(_p(a), _p(bt), _p(c), _p(c2), _p(bias), _p(res), M, N, K, K, K, N,
                                    -1 if act is None else _ACT[act], float(p_drop), seed, _stream()), "mgx_gemm_nt_bf16")
     return c if act is None else (c, c2)
 
 
-def gemm_nt_dfac(dy, bt, fac):
+FAC_ZERO = 27
+FAC_STEP = {"gelu": float(__import__("numpy").array([0x3BA3D700], dtype="uint32").view("float32")[0]), "relu": 2.0 ** -7}
+
+
+def decode_fac(fac, act):
+    """fp32 values of the derivative-factor codes gemm_nt(..., act=act) stores: act'(pre) * mask, without the
+    1 / (1 - p) of dropout (include/mgx.h).  For tests and diagnostics; the kernels decode in their epilogue."""
+    return (fac.to(torch.float32) - FAC_ZERO) * FAC_STEP[act]
+
+
+def gemm_nt_dfac(dy, bt, fac, act, p_drop=0.0):
     """Backward through `dropout(act(pre))` fused into the dgrad GEMM that produces its incoming gradient:
-    dpre[M,N] = (dy[M,K] @ bt[N,K]^T) * fac, with fac = act'(pre) * mask/(1-p) as gemm_nt(..., act=...) left it, and
+    dpre[M,N] = (dy[M,K] @ bt[N,K]^T) * fac / (1-p), with fac = the uint8 codes of act'(pre) * mask as
+    gemm_nt(..., act=act, p_drop=p_drop) left them, and
     dbias[N] = dpre.sum(0) in fp32 (per-row-tile partial sums, reduced by the library in a fixed order).  Replaces one
     GEMM output + one bias_act_bwd pass."""
     _need(dy, "dy", torch.bfloat16)
     _need(bt, "bt", torch.bfloat16)
-    _need(fac, "fac", torch.bfloat16)
+    _need(fac, "fac", torch.uint8)
     M, K = dy.shape
     N, K2 = bt.shape
     if K != K2 or K % 64 or N % 8 or fac.shape != (M, N):
@@ -294,8 +306,8 @@ def gemm_nt_dfac(dy, bt, fac):
     part = torch.empty(int(lib.mgx_gemm_nt_dfac_colpart_floats(M, N)), dtype=torch.float32, device=dy.device)
     dbias = torch.empty(N, dtype=torch.float32, device=dy.device)
     with _timed("gemm_nt", 2.0 * M * N * K):
-        check(lib.mgx_gemm_nt_dfac_bf16(_p(dy), _p(bt), _p(fac), _p(c), _p(part), _p(dbias), M, N, K, K, K, N, _stream()),
-              "mgx_gemm_nt_dfac_bf16")
+        check(lib.mgx_gemm_nt_dfac_bf16(_p(dy), _p(bt), _p(fac), _p(c), _p(part), _p(dbias), M, N, K, K, K, N, _ACT[act],
+                                        float(p_drop), _stream()), "mgx_gemm_nt_dfac_bf16")
     return c, dbias
 
 
@@ -803,7 +815,7 @@ class _DecoderBlock(torch.autograd.Function):
         dh2 = dh2.reshape(T, d).contiguous()
         dz2, _, dg2, dbe2, db2 = ln_residual_bwd(dh2, None, z2, mean2, rstd2, W.m_g2, want_dsum=True)
         if mfma:
-            dpre, db1 = gemm_nt_dfac(dz2, W.w2_t, pre)                                  # dz2 @ w2 through act' (+ db1)
+            dpre, db1 = gemm_nt_dfac(dz2, W.w2_t, pre, act, p)                          # dz2 @ w2 through act' (+ db1)
             # the two weight gradients of the MLP in one launch: [d, ff] and [ff, d]
             dw2, dw1 = gemm_tn_pair(dz2, hact, dpre, h1, grad_slot(W.m_w2, (d, hact.shape[1])),
                                     grad_slot(W.m_w1, (dpre.shape[1], d)))

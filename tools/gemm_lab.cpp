@@ -13,7 +13,8 @@
 extern "C" {
 int mgx_gemm_nt_bf16(const void*, const void*, void*, void*, const float*, const void*, int, int, int, int, int, int, int,
                      float, unsigned long long, void*);
-int mgx_gemm_nt_dfac_bf16(const void*, const void*, const void*, void*, float*, float*, int, int, int, int, int, int, void*);
+int mgx_gemm_nt_dfac_bf16(const void*, const void*, const void*, void*, float*, float*, int, int, int, int, int, int, int, float,
+                          void*);
 long mgx_gemm_nt_dfac_colpart_floats(int, int);
 long mgx_gemm_tn_workspace_floats(int, int, int, int*);
 int mgx_gemm_tn_bf16(const void*, const void*, void*, float*, int, int, int, int, int, int, void*);
@@ -136,8 +137,8 @@ static void run_nt(int M, int N, int K, int rounds, int reps) {
     auto launch = [&](const Variant& v) -> int {
         switch (v.kind) {
             case 3: return mgx_gemm_nt_bf16(A, Bt, C, nullptr, bias, nullptr, M, N, K, K, K, N, -1, 0.f, 0, nullptr);
-            case 5: return mgx_gemm_nt_dfac_bf16(A, Bt, pre, C, colpart, nullptr, M, N, K, K, K, N, nullptr);
-            case 8: return mgx_gemm_nt_dfac_bf16(A, Bt, pre, C, nullptr, nullptr, M, N, K, K, K, N, nullptr);
+            case 5: return mgx_gemm_nt_dfac_bf16(A, Bt, pre, C, colpart, nullptr, M, N, K, K, K, N, 0, 0.1f, nullptr);
+            case 8: return mgx_gemm_nt_dfac_bf16(A, Bt, pre, C, nullptr, nullptr, M, N, K, K, K, N, 0, 0.1f, nullptr);
             case 9: return mgx_gemm_nt_bf16(A, Bt, C, nullptr, bias, pre, M, N, K, K, K, N, -1, 0.f, 0, nullptr);
             case 7: return mgx_gemm_nt_bf16(A, Bt, C, C2, bias, nullptr, M, N, K, K, K, N, 1, 0.f, 1234, nullptr);
             case 6: return mgx_gemm_nt_bf16(A, Bt, C, C2, bias, nullptr, M, N, K, K, K, N, 0, 0.f, 1234, nullptr);
