@@ -30,7 +30,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0         # HBM3E spec, same table
-TRAFFIC_FILE = "r02d_traffic_pmc.json"
+TRAFFIC_FILE = "r03a_traffic_pmc.json"
 
 
 def pmc_traffic(key):
@@ -255,6 +255,8 @@ def bench_training(a, workload, B, S, steps, warmup, device, rank, world, force_
         hbm_lines.append({"bound": "hbm", "kernel": hbm_labels[name], "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                           "frac": ach / PEAK_HBM_GBS, "launches_timed": len(ev), "avg_launch_ms": tot_ms / len(ev),
                           "bytes_per_launch": by / len(ev), "ms_per_step": tot_ms / EVENT_STEPS})
+    if ddp is not None:
+        ddp.close()                                      # the next workload builds its own bucketer (and CE hook)
     out = {
         "metric": "training tokens/sec", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",

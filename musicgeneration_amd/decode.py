@@ -255,7 +255,10 @@ def sample_next_plus_one(model, seq: torch.Tensor, idx: int = 1, deterministic: 
     sl = (lambda a, b: seq[:, :, a:b]) if separated else (lambda a, b: seq[:, a:b])
     if idx >= 2:
         # positions 0..idx-2 are final before the first step
-        dec.rows(sl(0, idx - 1), 0)                       # flash kernel when > 4 rows, decode kernel otherwise
+        # prefill: only the K/V of the primer matter (flash kernel when > 4 rows, decode kernel otherwise); the head is
+        # not evaluated
+        with torch.no_grad():
+            dec.trunk(model.embed_tokens(sl(0, idx - 1), dec.dtype), 0)
     steps = range(idx, L - 1)
     if progress is not None:
         steps = progress(steps)
