@@ -229,10 +229,7 @@ int mgx_attn_fwd_mfma(int mode, const void* qkv, const float* slopes, const void
     if (mode == 1) return mgx_rel_fwd_mfma(qkv, E, out, lse, B, S, H, dh, max_seq, st);
     MGX_REQUIRE(mode == 0, MGX_EUNSUPPORTED, "mgx_attn_fwd_mfma: mode %d", mode);
     const float c = LOG2E / sqrtf((float)dh);
-#ifndef FWD_NW
-#define FWD_NW 8
-#endif
-    constexpr int NW = FWD_NW;                           // waves (x 32 queries) per workgroup
+    constexpr int NW = 8;                                // waves (x 32 queries) per workgroup
     const int nqb = (S + 32 * NW - 1) / (32 * NW);
     const long ppx = ((B * H + 7) / 8 + FWD_GROUP - 1) / FWD_GROUP * FWD_GROUP;       // pair slots per XCD
     MGX_REQUIRE(8 * ppx * nqb < (1L << 31), MGX_EUNSUPPORTED, "mgx_attn_fwd_mfma: too many workgroups");
