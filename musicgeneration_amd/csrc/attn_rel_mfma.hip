@@ -23,33 +23,60 @@
 namespace {
 
 constexpr int REL_NW = 4;        // waves (x 32 rows) per workgroup
-constexpr int SKS = 68;          // ring row stride in floats (272 B: 16-byte reads of 16 consecutive lanes spread over all banks)
 
 // ---- the skew ring (query-on-lane kernels) ----------------------------------------------------
 // G layout: accumulator of Er_blk . Q^T : lane = (query i_l, half h5), register e <-> distance
 //           Rb + 8*(e>>2) + 4*h5 + (e&3)
 // S layout: accumulator of K_blk . Q^T  : register e <-> key jb + 8*(e>>2) + 4*h5 + (e&3)
-__device__ __forceinline__ void ring_put_g(float* ring, const f32x16& g, int Rb, int l31, int h5) {
-    float* row = ring + l31 * SKS;
+// Physical image: the 64 positions of a row are two 32-position PLANES, RING_PLANE bytes apart; a wave's plane is
+// 32 rows x 128 B whose 16-byte quads are XOR-swizzled with three bits of i_l, chosen (by search) so that the scalar
+// accesses of 32 lanes, the 16-byte reads of 16 lanes and the 16-byte writes of 8 lanes each touch distinct banks.  Rb and R0 are multiples of 32, so a step of the walk only moves an access to
+// the other plane: every address is a per-lane constant (RingMap, computed once) XOR a wave-uniform plane bit.  (The
+// round-1 form computed (r - i_l - 1) & 63 per element: ~130 VALU instructions of address arithmetic per key block.)
+constexpr unsigned RING_PLANE = 0x4000;            // >= REL_NW * 4096, one bit
+constexpr unsigned RING_BYTES = 2 * RING_PLANE;    // all waves of the workgroup
+__device__ __forceinline__ unsigned ring_flip(int Rb) { return (unsigned)(Rb & 32) << 9; }   // odd block -> RING_PLANE
+
+struct RingMap {
+    unsigned dist[16];   // distance coordinates: the lane's 16 accumulator elements of an even block (scalar accesses)
+    unsigned key[4];     // key coordinates: the lane's 4 quads of an even block (16-byte accesses)
+    // ring_off: byte offset of the ring area in the workgroup's LDS; a multiple of RING_BYTES
+    __device__ __forceinline__ RingMap(unsigned ring_off, int w, int l31, int h5) {
+        const unsigned row = ring_off + 4096u * w + 128u * l31;
+        const unsigned f = ((l31 >> 1) & 3) | ((((l31 >> 3) ^ l31) & 1) << 2);   // conflict-free for all four access kinds
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int r = Rb + 8 * (e >> 2) + 4 * h5 + (e & 3);
-        row[(r - l31 - 1) & 63] = g[e];
+        for (int e = 0; e < 16; ++e) {
+            const int u = 8 * (e >> 2) + 4 * h5 + (e & 3) - l31 - 1;                  // position - Rb, in [-32, 30]
+            dist[e] = row + (u < 0 ? RING_PLANE : 0u) + 16u * ((((unsigned)u & 31) >> 2) ^ f) + 4u * ((unsigned)u & 3);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) key[g] = row + RING_PLANE + 16u * ((unsigned)(7 - 2 * g - h5) ^ f);   // positions R0 - 8g - 4h5 - 4 ..
     }
+};
+__device__ __forceinline__ void ring_put_g(char* smem, const RingMap& rm, const f32x16& g, int Rb) {
+    const unsigned fl = ring_flip(Rb);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) *reinterpret_cast<float*>(smem + (rm.dist[e] ^ fl)) = g[e];
 }
-__device__ __forceinline__ void ring_get_s(const float* ring, f32x16& s, int R0, int l31, int h5) {
-    const float* row = ring + l31 * SKS;
+// the same 16 elements back, for the distance block [R0, R0 + 32) (register e <-> distance R0 + 8*(e>>2) + 4*h5 + (e&3))
+__device__ __forceinline__ void ring_get_g(const char* smem, const RingMap& rm, f32x16& g, int R0) {
+    const unsigned fl = ring_flip(R0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) g[e] = *reinterpret_cast<const float*>(smem + (rm.dist[e] ^ fl));
+}
+__device__ __forceinline__ void ring_get_s(const char* smem, const RingMap& rm, f32x16& s, int R0) {
+    const unsigned fl = ring_flip(R0);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(row + ((R0 - 8 * g - 4 * h5 - 4) & 63));
+        const f32x4 v = *reinterpret_cast<const f32x4*>(smem + (rm.key[g] ^ fl));
         s[4 * g + 0] = v[3];
         s[4 * g + 1] = v[2];
         s[4 * g + 2] = v[1];
         s[4 * g + 3] = v[0];
     }
 }
-__device__ __forceinline__ void ring_put_s(float* ring, const f32x16& s, int R0, int l31, int h5) {
-    float* row = ring + l31 * SKS;
+__device__ __forceinline__ void ring_put_s(char* smem, const RingMap& rm, const f32x16& s, int R0) {
+    const unsigned fl = ring_flip(R0);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 v;
@@ -57,12 +84,12 @@ __device__ __forceinline__ void ring_put_s(float* ring, const f32x16& s, int R0,
         v[2] = s[4 * g + 1];
         v[1] = s[4 * g + 2];
         v[0] = s[4 * g + 3];
-        *reinterpret_cast<f32x4*>(row + ((R0 - 8 * g - 4 * h5 - 4) & 63)) = v;
+        *reinterpret_cast<f32x4*>(smem + (rm.key[g] ^ fl)) = v;
     }
 }
 
-// Er rows Rb + l31 as an MFMA operand (row on the lane, 8 consecutive d per lane and k-step);
-// Er[r] = E[h, M-1-r]; rows outside [0, M) are clamped (their products are never used).
+// Er rows Rb + l31 as an MFMA operand (row on the lane, 8 consecutive d per lane and k-step), straight from HBM (the
+// dK/dV kernel); Er[r] = E[h, M-1-r]; rows outside [0, M) are clamped (their products are never used).
 template <int DH>
 __device__ __forceinline__ void load_er_rows(bf16x8 (&ef)[DH / 16], const bf16_t* Eh, int M, int Rb, int l31, int h5) {
     int idx = M - 1 - (Rb + l31);
@@ -72,19 +99,48 @@ __device__ __forceinline__ void load_er_rows(bf16x8 (&ef)[DH / 16], const bf16_t
     for (int ks = 0; ks < DH / 16; ++ks) ef[ks] = *reinterpret_cast<const bf16x8*>(p + 16 * ks);
 }
 
+// ---- Er as a third tile stream (query-on-lane kernels) ---------------------------------------------------------
+// Er tile T = distances [64 T, 64 T + 64) in the K / V image format (image row i <-> table row M-1-64T-i, clamped: a
+// clamped row only meets masked keys).  A workgroup at key tile j0 touches the distance blocks (q0 - j0)/32 - 2 .. + 3:
+// three tiles, of which ONE is new per key tile; they live in three LDS slots (tile T in slot T mod 3) and are moved
+// with the K / V tiles (64 full lines per key tile and workgroup).  Round 1-2 had every wave gather its own 32 rows
+// per key block (and the dQ kernel its ErT pieces) with per-lane 16-byte loads: 8-12 vector-memory instructions of 32
+// cache lines each per block and wave, and the texture path - not MFMA, VALU or LDS - set the kernels' pace (measured
+// by removing those loads: dQ 887 -> 525 us, forward 401 -> 316 us at B8 S4096 dh64).
+template <int DH, int NT>
+__device__ __forceinline__ void er_tile_load(TileRegs<DH, NT>& t, const bf16_t* Eh, int M, int T, int tid) {
+#pragma unroll
+    for (int n = 0; n < 8 * DH / NT; ++n) {
+        int row, ch;
+        tile_elem<DH>(tid + NT * n, row, ch);
+        const int idx = min(max(M - 1 - (64 * T + row), 0), M - 1);
+        t.v[n] = *reinterpret_cast<const bf16x8*>(Eh + ((unsigned)idx * (unsigned)DH + (unsigned)(ch * 8)));
+    }
+}
+__device__ __forceinline__ int er_slot(int T) { return (T + 6) % 3; }      // T >= -6
+
+// LDS of the query-on-lane kernels: rings | K | V | 3 Er tiles
+template <int DH>
+struct RelLds {
+    static constexpr int TB = Img<DH>::TILE_BYTES;
+    static constexpr int K = RING_BYTES, V = K + TB, ER = V + TB, BYTES = ER + 3 * TB;
+};
+
 // ===========================================================================
 // forward
 // ===========================================================================
 template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void rel_fwd_mfma_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(64 * NW, (DH == 128 ? 1 : 2)) void rel_fwd_mfma_kernel(const bf16_t* __restrict__ qkv,
                                                                const bf16_t* __restrict__ E,
                                                                bf16_t* __restrict__ out, float* __restrict__ lse,
                                                                int S, int H, int M, float c /* scale*log2e */) {
     constexpr int NT = 64 * NW, QB = 32 * NW, TB = Img<DH>::TILE_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 x (K image, V image), then NW rings
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    using L = RelLds<DH>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h5 = lane >> 5;
-    float* ring = reinterpret_cast<float*>(smem + 4 * TB) + w * 32 * SKS;
+    static_assert(NW == 4 && NW * 4096 <= RING_PLANE, "the Er window is three tiles for 128 queries per workgroup");
+    const RingMap rm(0, w, l31, h5);
     const int qb = gridDim.z - 1 - blockIdx.z;
     const int q0 = qb * QB, qw0 = q0 + 32 * w;
     const int b = blockIdx.y, h = blockIdx.x;
@@ -110,47 +166,43 @@ __global__ __launch_bounds__(64 * NW, 2) void rel_fwd_mfma_kernel(const bf16_t* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
 
-    // distance blocks are consumed in descending order qw0, qw0-32, ..., 0: one block ahead in registers
-    bf16x8 ef[DH / 16];
-    auto g_block = [&](int Rb) {                           // G[Rb..Rb+32) -> ring; prefetch the next block's Er rows
+    // distance blocks are consumed in descending order qw0, qw0-32, ..., 0
+    auto g_block = [&](int Rb) {                           // G[Rb..Rb+32) = Er_blk . Q^T -> ring
+        const char* ep = smem + L::ER + er_slot(Rb >> 6) * TB;
+        const int tbe = (Rb >> 5) & 1;
         f32x16 g;
 #pragma unroll
         for (int e = 0; e < 16; ++e) g[e] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < DH / 16; ++ks) g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ef[ks], qf[ks], g, 0, 0, 0);
-        if (Rb >= 32) load_er_rows<DH>(ef, Eh, M, Rb - 32, l31, h5);
-        ring_put_g(ring, g, Rb, l31, h5);
+        for (int ks = 0; ks < DH / 16; ++ks)
+            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(ep + la.row_read(tbe, ks)), qf[ks], g, 0, 0, 0);
+        ring_put_g(smem, rm, g, Rb);
     };
-    if (qw0 < S) {
-        load_er_rows<DH>(ef, Eh, M, qw0, l31, h5);
-        g_block(qw0);
-    }
 
     const int kmax = min(q0 + QB, S);
     const int ntiles = (kmax + 63) / 64;
-    TileRegs<DH, NT> kr, vr;
+    const int T00 = q0 >> 6;                               // Er tiles T00 - t - 1 .. T00 - t + 1 serve key tile t
+    TileRegs<DH, NT> kr, vr, er;
+#pragma unroll
+    for (int i = -1; i <= 1; ++i) {
+        er_tile_load<DH, NT>(er, Eh, M, T00 + i, tid);
+        tile_store<DH, NT>(er, smem + L::ER + er_slot(T00 + i) * TB, tid);
+    }
     tile_load<DH, NT>(kr, kp, rs, 0, S, tid);
     tile_load<DH, NT>(vr, vp, rs, 0, S, tid);
-    tile_store<DH, NT>(kr, smem, tid);
-    tile_store<DH, NT>(vr, smem + TB, tid);
+    tile_store<DH, NT>(kr, smem + L::K, tid);
+    tile_store<DH, NT>(vr, smem + L::V, tid);
     if (ntiles > 1) {
         tile_load<DH, NT>(kr, kp, rs, 64, S, tid);
         tile_load<DH, NT>(vr, vp, rs, 64, S, tid);
+        er_tile_load<DH, NT>(er, Eh, M, T00 - 2, tid);
     }
     __syncthreads();
+    if (qw0 < S) g_block(qw0);
+    const char* Ks = smem + L::K;
+    const char* Vs = smem + L::V;
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * 64;
-        const char* Ks = smem + (t & 1) * 2 * TB;
-        const char* Vs = Ks + TB;
-        if (t + 1 < ntiles) {
-            char* Kn = smem + ((t + 1) & 1) * 2 * TB;
-            tile_store<DH, NT>(kr, Kn, tid);
-            tile_store<DH, NT>(vr, Kn + TB, tid);
-        }
-        if (t + 2 < ntiles) {
-            tile_load<DH, NT>(kr, kp, rs, j0 + 128, S, tid);
-            tile_load<DH, NT>(vr, vp, rs, j0 + 128, S, tid);
-        }
         if (j0 <= qw0 + 31 && qw0 < S) {                  // wave-uniform
             f32x16 s[2];
 #pragma unroll
@@ -158,7 +210,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rel_fwd_mfma_kernel(const bf16_t* 
                 const int R0 = qw0 - j0 - 32 * tb;        // distance of (query qw0, key block start)
                 if (R0 >= 0) {
                     if (R0 >= 32) g_block(R0 - 32);
-                    ring_get_s(ring, s[tb], R0, l31, h5);
+                    ring_get_s(smem, rm, s[tb], R0);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) s[tb][e] = 0.f;
@@ -215,6 +267,16 @@ __global__ __launch_bounds__(64 * NW, 2) void rel_fwd_mfma_kernel(const bf16_t* 
                     }
                 }
         }
+        if (t + 1 == ntiles) break;
+        __syncthreads();                                   // tile t and Er tile T00 - t + 1 are dead
+        tile_store<DH, NT>(kr, smem + L::K, tid);
+        tile_store<DH, NT>(vr, smem + L::V, tid);
+        tile_store<DH, NT>(er, smem + L::ER + er_slot(T00 - t - 2) * TB, tid);
+        if (t + 2 < ntiles) {
+            tile_load<DH, NT>(kr, kp, rs, j0 + 128, S, tid);
+            tile_load<DH, NT>(vr, vp, rs, j0 + 128, S, tid);
+            er_tile_load<DH, NT>(er, Eh, M, T00 - t - 3, tid);
+        }
         __syncthreads();
     }
     const float lt = half_swap_sum(l);
@@ -237,34 +299,22 @@ __global__ __launch_bounds__(64 * NW, 2) void rel_fwd_mfma_kernel(const bf16_t* 
 // ===========================================================================
 // backward
 // ===========================================================================
-// ErT[h][d][r] = Er[r][d] = E[h, M-1-r, d] for r < M, zero up to Mp = round_up(M, 32): the operand of
-// dQ += dG . Er needs Er with the distance as the contiguous (reduced) index.
-__global__ __launch_bounds__(256) void rel_ert_kernel(const bf16_t* __restrict__ E, bf16_t* __restrict__ ErT, int H,
-                                                       int M, int Mp, int DH) {
-    const long n = (long)H * DH * Mp;
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
-    const int r = (int)(t % Mp);
-    const long u = t / Mp;
-    const int d = (int)(u % DH);
-    const int h = (int)(u / DH);
-    ErT[t] = r < M ? E[((long)h * M + (M - 1 - r)) * DH + d] : (bf16_t)0.f;
-}
-
 // dQ: query on the lane.  Per 32-key block (distance R0 = qw0 - jb of its first key):
 //   S^T = K.Q^T + skew(G)   dP^T = V.dO^T - delta   dS^T = P^T*dP^T*scale   dQ^T += K^T.dS^T
 //   ring <- dS^T (in place of the consumed G entries); block R0 of dG is then complete:
-//   dQ^T += ErT[:, R0..R0+32) . dG^T
+//   dQ^T += Er[R0..R0+32)^T . dG^T      (transposed reads of the Er tile that gave G one block earlier)
 template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void rel_bwd_dq_mfma_kernel(
+__global__ __launch_bounds__(64 * NW, (DH == 128 ? 1 : 2)) void rel_bwd_dq_mfma_kernel(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qkv, const float* __restrict__ lse,
-    const float* __restrict__ delta, const bf16_t* __restrict__ E, const bf16_t* __restrict__ ErT,
-    bf16_t* __restrict__ dqkv, char* __restrict__ dg, int nrb, int S, int H, int M, int Mp, float c, float scale) {
+    const float* __restrict__ delta, const bf16_t* __restrict__ E, bf16_t* __restrict__ dqkv, char* __restrict__ dg,
+    int nrb, int S, int H, int M, float c, float scale) {
     constexpr int NT = 64 * NW, QB = 32 * NW, TB = Img<DH>::TILE_BYTES;
+    using L = RelLds<DH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h5 = lane >> 5;
-    float* ring = reinterpret_cast<float*>(smem + 4 * TB) + w * 32 * SKS;
+    static_assert(NW == 4 && NW * 4096 <= RING_PLANE, "the Er window is three tiles for 128 queries per workgroup");
+    const RingMap rm(0, w, l31, h5);
     const int qb = gridDim.z - 1 - blockIdx.z;
     const int q0 = qb * QB, qw0 = q0 + 32 * w;
     const int b = blockIdx.y, h = blockIdx.x;
@@ -274,7 +324,6 @@ __global__ __launch_bounds__(64 * NW, 2) void rel_bwd_dq_mfma_kernel(
     const bf16_t* vp = base + 2L * H * DH;
     const bf16_t* gp = dout + (long)b * S * H * DH + (long)h * DH;
     const bf16_t* Eh = E + (long)h * M * DH;
-    const bf16_t* Et = ErT + (long)h * DH * Mp + (long)l31 * Mp + 8 * h5;     // + 32*dblk*Mp + Rb + 16*s2
     const LaneAddr<DH> la(lane);
 
     const int qi = qw0 + l31;
@@ -295,25 +344,25 @@ __global__ __launch_bounds__(64 * NW, 2) void rel_bwd_dq_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
 
-    bf16x8 ef[DH / 16];
     auto g_block = [&](int Rb) {
+        const char* ep = smem + L::ER + er_slot(Rb >> 6) * TB;
+        const int tbe = (Rb >> 5) & 1;
         f32x16 g;
 #pragma unroll
         for (int e = 0; e < 16; ++e) g[e] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < DH / 16; ++ks) g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ef[ks], qf[ks], g, 0, 0, 0);
-        if (Rb >= 32) load_er_rows<DH>(ef, Eh, M, Rb - 32, l31, h5);
-        ring_put_g(ring, g, Rb, l31, h5);
+        for (int ks = 0; ks < DH / 16; ++ks)
+            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(ep + la.row_read(tbe, ks)), qf[ks], g, 0, 0, 0);
+        ring_put_g(smem, rm, g, Rb);
     };
     // dG of this wave's 32 queries goes to HBM block by block for the dE GEMM (gemm_tn.hip, MODE 1): 2 KiB blocks
-    // [query unit][distance block][2 distance halves][32 queries][16 distances]; the MFMA operand of dQ += ErT . dG^T
-    // (8 consecutive distances of the lane's query) is the 16-byte piece as it stands.  That GEMM walks 256-distance
-    // tiles and reads, for the units inside a tile's own 256 queries, the blocks above the diagonal, which nobody
-    // computes: zeros, written here.
+    // [query unit][distance block][2 distance halves][32 queries][16 distances]; the 16-byte piece of a lane is its
+    // MFMA operand as it stands, so within a 16-distance half the stored position 8*h5 + 4*c + k holds distance
+    // 8*c + 4*h5 + k (bits 2 and 3 swapped; rel_de_reduce_kernel reads the GEMM's rows through the same swap).  That
+    // GEMM walks 256-distance tiles and reads, for the units inside a tile's own 256 queries, the blocks above the
+    // diagonal, which nobody computes: zeros, written here.
     char* const dgp = dg + ((((long)b * H + h) * nrb + (qw0 >> 5)) * nrb << 11) + 32 * l31 + 16 * h5;
     if (qw0 < S) {
-        load_er_rows<DH>(ef, Eh, M, qw0, l31, h5);
-        g_block(qw0);
         const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int rb = (qw0 >> 5) + 1; rb <= min((qw0 >> 5) | 7, nrb - 1); ++rb) {
             *reinterpret_cast<bf16x8*>(dgp + ((long)rb << 11)) = z;
@@ -323,46 +372,38 @@ __global__ __launch_bounds__(64 * NW, 2) void rel_bwd_dq_mfma_kernel(
 
     const int kmax = min(q0 + QB, S);
     const int ntiles = (kmax + 63) / 64;
-    TileRegs<DH, NT> kr, vr;
+    const int T00 = q0 >> 6;                               // Er tiles T00 - t - 1 .. T00 - t + 1 serve key tile t
+    TileRegs<DH, NT> kr, vr, er;
+#pragma unroll
+    for (int i = -1; i <= 1; ++i) {
+        er_tile_load<DH, NT>(er, Eh, M, T00 + i, tid);
+        tile_store<DH, NT>(er, smem + L::ER + er_slot(T00 + i) * TB, tid);
+    }
     tile_load<DH, NT>(kr, kp, rs, 0, S, tid);
     tile_load<DH, NT>(vr, vp, rs, 0, S, tid);
-    tile_store<DH, NT>(kr, smem, tid);
-    tile_store<DH, NT>(vr, smem + TB, tid);
+    tile_store<DH, NT>(kr, smem + L::K, tid);
+    tile_store<DH, NT>(vr, smem + L::V, tid);
     if (ntiles > 1) {
         tile_load<DH, NT>(kr, kp, rs, 64, S, tid);
         tile_load<DH, NT>(vr, vp, rs, 64, S, tid);
+        er_tile_load<DH, NT>(er, Eh, M, T00 - 2, tid);
     }
     __syncthreads();
+    if (qw0 < S) g_block(qw0);
+    const char* Ks = smem + L::K;
+    const char* Vs = smem + L::V;
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * 64;
-        const char* Ks = smem + (t & 1) * 2 * TB;
-        const char* Vs = Ks + TB;
-        if (t + 1 < ntiles) {
-            char* Kn = smem + ((t + 1) & 1) * 2 * TB;
-            tile_store<DH, NT>(kr, Kn, tid);
-            tile_store<DH, NT>(vr, Kn + TB, tid);
-        }
-        if (t + 2 < ntiles) {
-            tile_load<DH, NT>(kr, kp, rs, j0 + 128, S, tid);
-            tile_load<DH, NT>(vr, vp, rs, j0 + 128, S, tid);
-        }
         if (j0 <= qw0 + 31 && qw0 < S) {
             const int dj = qi - j0 - 4 * h5;
-            const bool diag = j0 + 63 > qw0;
+            const bool diag = j0 + 63 > qw0;                       // wave-uniform
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) {
                 const int R0 = qw0 - j0 - 32 * tb;
                 if (R0 < 0) continue;                              // wave-uniform: block fully masked
-                // operand of the dG product for this step's completed distance block, fetched early
-                bf16x8 etf[2][DH / 32];
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int d = 0; d < DH / 32; ++d)
-                        etf[s2][d] = *reinterpret_cast<const bf16x8*>(Et + (long)(32 * d) * Mp + R0 + 16 * s2);
                 if (R0 >= 32) g_block(R0 - 32);
                 f32x16 sc, dp;
-                ring_get_s(ring, sc, R0, l31, h5);
+                ring_get_s(smem, rm, sc, R0);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dp[r] = ndelta;
 #pragma unroll
@@ -371,12 +412,15 @@ __global__ __launch_bounds__(64 * NW, 2) void rel_bwd_dq_mfma_kernel(
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(Vs + la.row_read(tb, ks)), gf[ks], dp, 0, 0, 0);
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float p = fast_exp2(fmaf(sc[r], c, -lse2));
-                    if (diag && (32 * tb + (r & 3) + 8 * (r >> 2) > dj)) p = 0.f;
-                    sc[r] = p * dp[r] * scale;
+                for (int r = 0; r < 16; ++r) sc[r] = fast_exp2(fmaf(sc[r], c, -lse2));
+                if (diag) {                                        // the diagonal tile only: a real branch
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (32 * tb + (r & 3) + 8 * (r >> 2) > dj) sc[r] = 0.f;
                 }
-                ring_put_s(ring, sc, R0, l31, h5);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] *= dp[r] * scale;
+                ring_put_s(smem, rm, sc, R0);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const bf16x8 dsf = pack8(sc, 8 * s2);
@@ -387,24 +431,38 @@ __global__ __launch_bounds__(64 * NW, 2) void rel_bwd_dq_mfma_kernel(
                     }
                 }
                 // distance block [R0, R0+32) of dG^T is complete (its other half came from the previous key block)
-                const float* row = ring + l31 * SKS;
+                f32x16 dgv;
+                ring_get_g(smem, rm, dgv, R0);
+                if (R0 == qw0) {                                   // key block 0: distances r > i (keys below 0) were never written
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (8 * (e >> 2) + 4 * h5 + (e & 3) > l31) dgv[e] = 0.f;
+                }
+                const char* ep = smem + L::ER + er_slot(R0 >> 6) * TB;
+                const int tbe = (R0 >> 5) & 1;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    bf16x8 dgf;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int r = R0 + 16 * s2 + 8 * h5 + e;
-                        const float v = row[(r - l31 - 1) & 63];
-                        dgf[e] = (bf16_t)((r > qi) ? 0.f : v);     // r > i: key index below 0, never written
-                    }
+                    const bf16x8 dgf = pack8(dgv, 8 * s2);
                     // written once, read once by the dE GEMM: non-temporal, so that the 1.07 GB do not push the K / V tiles
                     // out of L2 (relative backward 1.61 -> 1.55 ms per layer at B8 S4096)
                     __builtin_nontemporal_store(dgf, reinterpret_cast<bf16x8*>(dgp + ((long)(R0 >> 5) << 11) + 1024 * s2));
 #pragma unroll
-                    for (int d = 0; d < DH / 32; ++d)
-                        dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(etf[s2][d], dgf, dq[d], 0, 0, 0);
+                    for (int d = 0; d < DH / 32; ++d) {
+                        const bf16x8 et = lds_read_tr_pair(ep + la.tr_read(tbe, s2, 0, d), ep + la.tr_read(tbe, s2, 1, d));
+                        dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(et, dgf, dq[d], 0, 0, 0);
+                    }
                 }
             }
+        }
+        if (t + 1 == ntiles) break;
+        __syncthreads();                                   // tile t and Er tile T00 - t + 1 are dead
+        tile_store<DH, NT>(kr, smem + L::K, tid);
+        tile_store<DH, NT>(vr, smem + L::V, tid);
+        tile_store<DH, NT>(er, smem + L::ER + er_slot(T00 - t - 2) * TB, tid);
+        if (t + 2 < ntiles) {
+            tile_load<DH, NT>(kr, kp, rs, j0 + 128, S, tid);
+            tile_load<DH, NT>(vr, vp, rs, j0 + 128, S, tid);
+            er_tile_load<DH, NT>(er, Eh, M, T00 - t - 3, tid);
         }
         __syncthreads();
     }
@@ -452,7 +510,7 @@ __global__ __launch_bounds__(64 * NW, (DH == 128 ? 1 : 2)) void rel_bwd_dkv_mfma
     constexpr int NT = 64 * NW, KB = 32 * NW, TB = Img<DH>::TILE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (Q, dO images), stats, NW skew buffers
     float* stats = reinterpret_cast<float*>(smem + 4 * TB);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h5 = lane >> 5;
     float* skew = stats + 4 * 64 + w * 32 * BKS;
     const int jb0 = blockIdx.z * KB, jw0 = jb0 + 32 * w;
@@ -535,13 +593,15 @@ __global__ __launch_bounds__(64 * NW, (DH == 128 ? 1 : 2)) void rel_bwd_dkv_mfma
 #pragma unroll
                 for (int ks = 0; ks < DH / 16; ++ks) af[ks] = lds_read16(Qs + la.row_read(tb, ks));
                 {
+                    // (D = 0: the lower block holds distances < 0, i.e. keys above the diagonal, masked below; er_lo is
+                    // the clamped row set of the start, its product finite and unused)
                     f32x16 glo, ghi;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) glo[e] = ghi[e] = 0.f;
 #pragma unroll
                     for (int ks = 0; ks < DH / 16; ++ks) {
                         ghi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], er_hi[ks], ghi, 0, 0, 0);
-                        if (D > 0) glo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], er_lo[ks], glo, 0, 0, 0);
+                        glo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], er_lo[ks], glo, 0, 0, 0);
                     }
                     band_put(skew, glo, 0, l31, h5);
                     band_put(skew, ghi, 1, l31, h5);
@@ -568,12 +628,14 @@ __global__ __launch_bounds__(64 * NW, (DH == 128 ? 1 : 2)) void rel_bwd_dkv_mfma
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(Gs + la.row_read(tb, ks)), vf[ks], dp, 0, 0, 0);
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float p = fast_exp2(sc[r] * c);
-                    if (diag && (32 * tb + (r & 3) + 8 * (r >> 2) < di)) p = 0.f;
-                    sc[r] = p;
-                    dp[r] = p * dp[r] * scale;
+                for (int r = 0; r < 16; ++r) sc[r] = fast_exp2(sc[r] * c);
+                if (diag) {                                        // the diagonal tile only: a real branch
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (32 * tb + (r & 3) + 8 * (r >> 2) < di) sc[r] = 0.f;
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dp[r] *= sc[r] * scale;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const bf16x8 pf = pack8(sc, 8 * s2);
@@ -622,7 +684,8 @@ __global__ __launch_bounds__(256) void rel_de_reduce_kernel(const float* __restr
     const int r = M - 1 - row;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (r < Mp) {
-        const float* p = slabs + ((long)h * Mp + r) * dh + 4 * c4;
+        const int rp = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);     // the dQ kernel's storage order of a 16-distance half
+        const float* p = slabs + ((long)h * Mp + rp) * dh + 4 * c4;
         for (int b = 0; b < B; ++b) s += *reinterpret_cast<const f32x4*>(p + (long)b * H * Mp * dh);
     }
     *reinterpret_cast<f32x4*>(dE + idx * 4) = s;
@@ -634,7 +697,7 @@ void allow_smem(F* fn, size_t bytes) {
 }
 
 template <int DH>
-constexpr size_t rel_fwd_smem(int nw) { return (size_t)4 * Img<DH>::TILE_BYTES + (size_t)nw * 32 * SKS * sizeof(float); }
+constexpr size_t rel_fwd_smem(int) { return (size_t)RelLds<DH>::BYTES; }
 
 }  // namespace
 
@@ -672,18 +735,11 @@ int launch_rel_bwd(const void* dout, const void* qkv, const void* out, const flo
     const float scale = 1.0f / sqrtf((float)DH);
     const float c = LOG2E * scale;
     constexpr int NW = REL_NW;
-    const int M = max_seq, Mp = (M + 31) / 32 * 32;
+    const int M = max_seq;
     const int nrb = (S + 31) / 32;
     float* delta = ws;
     float* slabs = ws + ((long)B * H * S + 63) / 64 * 64;
     char* dg = reinterpret_cast<char*>(slabs + (long)B * H * nrb * 32 * DH);
-    // the dE buffer (fp32 [H,M,DH]) holds the transposed bf16 copy of E (H*DH*Mp*2 bytes <= its size
-    // since Mp <= 2M) until the reduction of the dE slabs, which runs last, overwrites it
-    bf16_t* ErT = reinterpret_cast<bf16_t*>(dE);
-    const long n_t = (long)H * DH * Mp;
-    hipLaunchKernelGGL(rel_ert_kernel, dim3((unsigned)((n_t + 255) / 256)), dim3(256), 0, st, (const bf16_t*)E, ErT, H, M,
-                       Mp, DH);
-    MGX_CHECK_LAUNCH("rel_ert");
     const long n_chunks = (long)B * S * H * (DH / 8);
     hipLaunchKernelGGL((attn_delta_mfma_kernel<DH>), dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st,
                        (const bf16_t*)dout, (const bf16_t*)out, delta, n_chunks, S, H);
@@ -696,8 +752,8 @@ int launch_rel_bwd(const void* dout, const void* qkv, const void* out, const flo
     MGX_CHECK_LAUNCH("rel_bwd_dkv_mfma");
     allow_smem(rel_bwd_dq_mfma_kernel<DH, NW>, rel_fwd_smem<DH>(NW));
     hipLaunchKernelGGL((rel_bwd_dq_mfma_kernel<DH, NW>), grid, dim3(64 * NW), rel_fwd_smem<DH>(NW), st,
-                       (const bf16_t*)dout, (const bf16_t*)qkv, lse, delta, (const bf16_t*)E, (const bf16_t*)ErT,
-                       (bf16_t*)dqkv, dg, nrb, S, H, M, Mp, c, scale);
+                       (const bf16_t*)dout, (const bf16_t*)qkv, lse, delta, (const bf16_t*)E, (bf16_t*)dqkv, dg, nrb, S, H,
+                       M, c, scale);
     MGX_CHECK_LAUNCH("rel_bwd_dq_mfma");
     // dE: a batched, causal TN GEMM over the dG blocks (one slab per (b, h)), then the sum over b into the table
     if (int rc = mgx_rel_de_from_dg(dg, qkv, slabs, B, S, H, DH, nrb, st)) return rc;

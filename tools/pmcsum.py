@@ -7,6 +7,6 @@ for r in csv.DictReader(open(f)):
     agg[k][r['Counter_Name']] += float(r['Counter_Value'])
     cnt[(k, r['Counter_Name'])] += 1
 for k, v in agg.items():
-    if 'attn' not in k and 'gemm' not in k.lower() and 'Cijk' not in k: continue
+    if not any(t in k.lower() for t in ('attn', 'gemm', 'cijk', 'rel_')): continue
     print(k)
     for c, val in v.items(): print(f"    {c:32s} {val / cnt[(k, c)]:16.1f}  (avg of {cnt[(k, c)]})")
