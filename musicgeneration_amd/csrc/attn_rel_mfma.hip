@@ -205,6 +205,37 @@ __global__ __launch_bounds__(64 * NW, (DH == 128 ? 1 : 2)) void rel_fwd_mfma_ker
         const int j0 = t * 64;
         if (j0 <= qw0 + 31 && qw0 < S) {                  // wave-uniform
             f32x16 s[2];
+            if (qw0 - j0 >= 64) {
+                // both key blocks lie wholly in the past: one straight-line block, the four products independent of
+                // each other and of the ring's round trips (LDS operations of a wave are executed in issue order,
+                // so the second G block may be written as soon as the first key block's reads have been ISSUED)
+                const int R0 = qw0 - j0;
+                const char* e0 = smem + L::ER + er_slot((R0 - 32) >> 6) * TB;
+                const char* e1 = smem + L::ER + er_slot((R0 - 64) >> 6) * TB;
+                const int t0 = ((R0 - 32) >> 5) & 1, t1 = t0 ^ 1;
+                f32x16 g0, g1, r0, r1;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) g0[e] = g1[e] = s[0][e] = s[1][e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < DH / 16; ++ks) {
+                    g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(e0 + la.row_read(t0, ks)), qf[ks], g0, 0, 0, 0);
+                    g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(e1 + la.row_read(t1, ks)), qf[ks], g1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < DH / 16; ++ks) {
+                    s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(Ks + la.row_read(0, ks)), qf[ks], s[0], 0, 0, 0);
+                    s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(Ks + la.row_read(1, ks)), qf[ks], s[1], 0, 0, 0);
+                }
+                ring_put_g(smem, rm, g0, R0 - 32);
+                ring_get_s(smem, rm, r0, R0);
+                ring_put_g(smem, rm, g1, R0 - 64);
+                ring_get_s(smem, rm, r1, R0 - 32);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    s[0][e] += r0[e];
+                    s[1][e] += r1[e];
+                }
+            } else
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) {
                 const int R0 = qw0 - j0 - 32 * tb;        // distance of (query qw0, key block start)
