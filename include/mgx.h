@@ -76,7 +76,8 @@ int mgx_rel_attn_fwd(const void* qkv, const void* E, void* out, float* lse,
 
 /* Autograd of the above.  dE [H,max_seq,dh] fp32, fully overwritten (rows < max_seq-S get zero).
  * workspace: mgx_rel_attn_bwd_workspace_floats(...) floats for the same shape and dtype flags: rowsum(dout*out)
- * and, on the bf16 MFMA path, the dG blocks the dQ kernel stores (B*H*ceil(S/32)^2 x 2 KiB) and the per-(b,h) fp32
+ * and, on the bf16 MFMA path, the dG blocks the dQ kernel stores (2 KiB per 32x32 block of the causal triangle, the rows of
+ * blocks padded to their 256-distance tile: about B*H*ceil(S/32)^2/2 x 2 KiB) and the per-(b,h) fp32
  * slabs of the dE GEMM over them. */
 long mgx_rel_attn_bwd_workspace_floats(int B, int S, int H, int dh, int max_seq, int dtype);
 int mgx_rel_attn_bwd(const void* dout, const void* qkv, const void* out, const float* lse,

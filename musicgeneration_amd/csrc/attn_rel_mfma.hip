@@ -387,12 +387,13 @@ __global__ __launch_bounds__(64 * NW, (DH == 128 ? 1 : 2)) void rel_bwd_dq_mfma_
         ring_put_g(smem, rm, g, Rb);
     };
     // dG of this wave's 32 queries goes to HBM block by block for the dE GEMM (gemm_tn.hip, MODE 1): 2 KiB blocks
-    // [query unit][distance block][2 distance halves][32 queries][16 distances]; the 16-byte piece of a lane is its
+    // [query unit: a staircase of rows, mgx_rel_dg_row][distance block][2 distance halves][32 queries][16 distances]; the
+    // 16-byte piece of a lane is its
     // MFMA operand as it stands, so within a 16-distance half the stored position 8*h5 + 4*c + k holds distance
     // 8*c + 4*h5 + k (bits 2 and 3 swapped; rel_de_reduce_kernel reads the GEMM's rows through the same swap).  That
     // GEMM walks 256-distance tiles and reads, for the units inside a tile's own 256 queries, the blocks above the
     // diagonal, which nobody computes: zeros, written here.
-    char* const dgp = dg + ((((long)b * H + h) * nrb + (qw0 >> 5)) * nrb << 11) + 32 * l31 + 16 * h5;
+    char* const dgp = dg + ((((long)b * H + h) * mgx_rel_dg_row(nrb) + mgx_rel_dg_row(qw0 >> 5)) << 11) + 32 * l31 + 16 * h5;
     if (qw0 < S) {
         const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int rb = (qw0 >> 5) + 1; rb <= min((qw0 >> 5) | 7, nrb - 1); ++rb) {
@@ -751,11 +752,11 @@ int mgx_rel_fwd_mfma(const void* qkv, const void* E, void* out, float* lse, int 
 
 bool mgx_rel_bwd_mfma_ready() { return true; }
 
-// workspace of the backward, in floats: delta [B,H,S] | dE slabs [B*H][32 nrb][dh] | dG blocks [B*H][nrb][nrb] x 2 KiB
+// workspace of the backward, in floats: delta [B,H,S] | dE slabs [B*H][32 nrb][dh] | dG blocks [B*H][staircase] x 2 KiB
 long mgx_rel_bwd_mfma_workspace_floats(int B, int S, int H, int dh) {
-    const long nrb = (S + 31) / 32;
+    const int nrb = (S + 31) / 32;
     const long delta = ((long)B * H * S + 63) / 64 * 64;
-    return delta + (long)B * H * nrb * 32 * dh + (long)B * H * nrb * nrb * 512;
+    return delta + (long)B * H * nrb * 32 * dh + (long)B * H * mgx_rel_dg_row(nrb) * 512;
 }
 int mgx_rel_de_from_dg(const void* dg, const void* qkv, float* slabs, int B, int S, int H, int dh, int nrb, hipStream_t st);   // gemm_tn.hip
 

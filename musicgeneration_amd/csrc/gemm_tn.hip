@@ -35,7 +35,8 @@ struct TnArgs {
     // MODE 1 (dE of the skew relative attention from the dG blocks the dQ kernel stored, attn_rel_mfma.hip):
     // A = blocked dG, B = the packed qkv (q third of b = 0, h = 0), C = fp32 slabs [B*H][M][N]; M = padded number
     // of distances, N = dh, K = S (queries)
-    int bk_bh, bk_h, bk_nrb;   // B*H, H, 32-distance blocks per 32-query unit row
+    int bk_bh, bk_h;           // B*H, H
+    long bk_blocks;            // 2-KiB dG blocks per (b, h): mgx_rel_dg_row(nrb), the staircase layout of attn_rel_mfma.hip
 };
 
 __device__ const bf16_t g_tn_zero16[8] = {};
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs g) {
         kend = g.K;
         split = bh;
         const int b = bh / g.bk_h, h = bh - b * g.bk_h;
-        Ab += ((long)bh * g.bk_nrb + (kbeg >> 5)) * g.bk_nrb * 2048;
+        Ab += (long)bh * g.bk_blocks * 2048;
         Bb += ((long)b * g.K * P.ldb + (long)h * P.N) * 2;
     }
     const int nk = (kend - kbeg + BK - 1) / BK;
@@ -166,15 +167,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(TnArgs g) {
             } else {
                 // query row srow of the K tile: unit srow >> 5, row srow & 31 of the block; 8 distances of block m >> 5
                 const int m = min(m0 + 128 * X + ch * 8, P.M - 8);
-                sa[X][i] = (unsigned)((((srow >> 5) * g.bk_nrb + (m >> 5)) * 2048) + ((m >> 4) & 1) * 1024 +
-                                      (srow & 31) * 32 + (m & 15) * 2);
+                // (the unit's row of blocks is added per stage: mgx_rel_dg_row, wave-uniform)
+                sa[X][i] = (unsigned)(((m >> 5) * 2048) + ((m >> 4) & 1) * 1024 + (srow & 31) * 32 + (m & 15) * 2);
             }
             sb[X][i] = (unsigned)(((long)srow * P.ldb + min(n0 + 128 * X + ch * 8, P.N - 8)) * 2);
         }
     char* const stage_base = smem + 2048 * w;
     auto stage_a = [&](int X, int d, int kt) {
         const int k0 = kbeg + min(kt, nk - 1) * BK;
-        const char* src = MODE == 0 ? Ab + (long)k0 * P.lda * 2 : Ab + (long)((k0 - kbeg) >> 5) * g.bk_nrb * 2048;
+        // MODE 1: query unit (k0 >> 5) + (srow >> 5), and srow >> 5 == w >> 2
+        const char* src = MODE == 0 ? Ab + (long)k0 * P.lda * 2 : Ab + mgx_rel_dg_row((k0 >> 5) + (w >> 2)) * 2048L;
         char* dst = stage_base + (2 * X + d) * HT;
         const char* p0 = src + sa[X][0];
         const char* p1 = src + sa[X][1];
@@ -440,14 +442,14 @@ extern "C" int mgx_gemm_tn_pair_bf16(const void* A0, const void* B0, void* C0, i
 }
 
 // skew relative attention backward, dEr slabs from the dG blocks of rel_bwd_dq_mfma_kernel (attn_rel_mfma.hip).
-// dg: [B*H][nrb query units][nrb distance blocks] blocks of 2 KiB; slabs: [B*H][32 nrb][dh] fp32
+// dg: [B*H][staircase of 2-KiB blocks: unit qu holds distance blocks 0 .. qu | 7, mgx_rel_dg_row]; slabs: [B*H][32 nrb][dh] fp32
 int mgx_rel_de_from_dg(const void* dg, const void* qkv, float* slabs, int B, int S, int H, int dh, int nrb, hipStream_t st) {
     MGX_REQUIRE(dh == 64 || dh == 128, MGX_EUNSUPPORTED, "rel dE from dG: dh=%d", dh);
     const int Mp = nrb * 32;
     const int rs = 3 * H * dh;
     MGX_REQUIRE(64L * rs < (1L << 30), MGX_EUNSUPPORTED, "rel dE from dG: row stride too large");
     TnArgs g{{{(const char*)dg, (const char*)qkv, slabs, Mp, dh, 0, rs}, {nullptr, nullptr, nullptr, 8, 8, 8, 8}},
-             0, 0, S, 0, B * H, H, nrb};
+             0, 0, S, 0, B * H, H, mgx_rel_dg_row(nrb)};
     const int nT = (min(Mp, (S + 31) / 32 * 32) + BM - 1) / BM;       // distance tiles that hold a distance <= S - 1
     const unsigned grid = (unsigned)(B * H * nT);
     if (S % BK == 0)

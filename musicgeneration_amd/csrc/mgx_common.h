@@ -75,3 +75,12 @@ __device__ __forceinline__ void mgx_keep_pair(unsigned long long seed, unsigned 
     k0 = (h & 0xFFFFu) >= thr16;
     k1 = (h >> 16) >= thr16;
 }
+
+// dG workspace of the skew relative attention backward (attn_rel_mfma.hip writes it, gemm_tn.hip MODE 1 reads it): 2-KiB
+// blocks (32 queries x 32 distances, bf16).  32-query unit qu holds the distance blocks 0 .. qu | 7 - the causal ones plus
+// the zero blocks that complete its 256-distance tile - so the rows form a staircase; mgx_rel_dg_row(qu) is the index of
+// unit qu's first block and mgx_rel_dg_row(nrb) the block count of one (batch, head): 8704 instead of 16384 at S = 4096.
+__host__ __device__ __forceinline__ long mgx_rel_dg_row(int qu) {
+    const long a = qu >> 3, r = qu & 7;
+    return 8 * (a + 1) * (4 * a + r);
+}
