@@ -220,7 +220,8 @@ bool mgx_attn_mfma_supported(int mode, int dh, int dtype, int S, int H, int max_
     // 32-bit byte offsets inside one batch element: S * (3*H*dh) * 2 bytes must stay below 2^31
     if (!(dtype == MGX_BF16 && (dh == 64 || dh == 128) && (long)S * 3 * H * dh * 2 < (1L << 31))) return false;
     if (mode == 0) return true;
-    // skew-relative mode: the backward reads a transposed copy of E with 16-byte loads
+    // skew-relative mode: E rows are fetched as 16-byte pieces of whole rows (any max_seq would do since round 3, when the
+    // transposed copy of E went away; the bound is kept as the tested envelope, other tables take the generic kernels)
     return mode == 1 && max_seq % 8 == 0 && max_seq >= 32 && (!backward || mgx_rel_bwd_mfma_ready());
 }
 
