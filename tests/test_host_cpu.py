@@ -27,6 +27,25 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.mgx_version() >= 100
 
 
+def test_relative_backward_workspace_holds_the_causal_staircase_only():
+    """Host arithmetic only (no GPU call): the dG blocks of the relative attention backward are stored as a staircase
+    (32-query unit qu owns distance blocks 0 .. qu | 7), not as the full square of round 2."""
+    from musicgeneration_amd import _lib
+    B, S, H, dh = 8, 4096, 8, 64
+    floats = _lib.lib.mgx_rel_attn_bwd_workspace_floats(B, S, H, dh, S, _lib.BF16)
+    nrb = S // 32
+    delta = B * H * S
+    slabs = B * H * nrb * 32 * dh
+    staircase = sum((qu | 7) + 1 for qu in range(nrb))            # 2-KiB blocks per (batch, head)
+    assert staircase == 8704 and staircase < 0.54 * nrb * nrb
+    assert floats == delta + slabs + B * H * staircase * 512
+    # ragged length: every unit still owns the blocks its 256-distance tile reads
+    S2 = 1000
+    nrb2 = (S2 + 31) // 32
+    got = _lib.lib.mgx_rel_attn_bwd_workspace_floats(1, S2, 1, dh, 1024, _lib.BF16)
+    assert got == (S2 + 63) // 64 * 64 + nrb2 * 32 * dh + sum((qu | 7) + 1 for qu in range(nrb2)) * 512
+
+
 def test_product_path_does_not_import_the_oracle():
     pkg = os.path.join(ROOT, "musicgeneration_amd")
     for dirpath, _, files in os.walk(pkg):
