@@ -630,11 +630,15 @@ __global__ __launch_bounds__(64 * NW, (DH == 128 ? 1 : 2)) void rel_bwd_dkv_mfma
                     f32x16 glo, ghi;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) glo[e] = ghi[e] = 0.f;
+                    // the two waves of a SIMD bunch their MFMAs: while one is inside a group it keeps the issue priority, so
+                    // the groups alternate instead of interleaving instruction by instruction (dK/dV 547 -> 534 us)
+                    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int ks = 0; ks < DH / 16; ++ks) {
                         ghi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], er_hi[ks], ghi, 0, 0, 0);
                         glo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], er_lo[ks], glo, 0, 0, 0);
                     }
+                    __builtin_amdgcn_s_setprio(0);
                     band_put(skew, glo, 0, l31, h5);
                     band_put(skew, ghi, 1, l31, h5);
                     // next block's distances: [D, D+32) becomes the lower block
@@ -654,11 +658,13 @@ __global__ __launch_bounds__(64 * NW, (DH == 128 ? 1 : 2)) void rel_bwd_dkv_mfma
                         dp[4 * g + k] = dn[k];
                     }
                 }
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int ks = 0; ks < DH / 16; ++ks) {
                     sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], kf[ks], sc, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read16(Gs + la.row_read(tb, ks)), vf[ks], dp, 0, 0, 0);
                 }
+                __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[r] = fast_exp2(sc[r] * c);
                 if (diag) {                                        // the diagonal tile only: a real branch
@@ -668,6 +674,7 @@ __global__ __launch_bounds__(64 * NW, (DH == 128 ? 1 : 2)) void rel_bwd_dkv_mfma
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dp[r] *= sc[r] * scale;
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const bf16x8 pf = pack8(sc, 8 * s2);
@@ -680,6 +687,7 @@ __global__ __launch_bounds__(64 * NW, (DH == 128 ? 1 : 2)) void rel_bwd_dkv_mfma
                         dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, dsf, dk[d], 0, 0, 0);
                     }
                 }
+                __builtin_amdgcn_s_setprio(0);
             }
         }
         __syncthreads();
