@@ -3,7 +3,8 @@
 // The activation epilogue writes dropout(act(pre)) and, for the backward, the derivative factor act'(pre) * mask as ONE
 // BYTE per element (a uniform code, see FacCode); the activation-backward dgrad is then (A . Bt^T) * fac / (1 - p): a
 // byte conversion and two multiplies per element instead of erf + exp + the dropout hash (the epilogue is serial with
-// the main loop on a CU), and half the bytes of a bf16 side tensor in both directions.
+// the main loop on a CU), and half the bytes of a bf16 side tensor in both directions.  In the GELU forward epilogue
+// both results of an element come from an LDS table indexed by the bf16 pre-activation (gelu_tab_off below).
 // Replaces Conv1d.forward (base_layers.py:54-57: reshape -> matmul -> +b), the nn.Linear calls of
 // DecoderBlock.forward (alibi_unified.py:90,92) and the dgrad GEMMs autograd derives from them.
 //
@@ -59,21 +60,29 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 }
 
 // gelu(x) = x * Phi(x) and d/dx gelu(x) = Phi(x) + x * phi(x) from one evaluation of erf (Abramowitz-Stegun 7.1.26,
-// |error| < 1.5e-7) and of exp(-x^2 / 2)
-__device__ __forceinline__ void gelu_val_grad(float x, float& y, float& dy) {
-    const float z = x * 0.70710678118654752440f;
-    const float az = fabsf(z);
+// |error| < 1.5e-7) and of exp(-x^2 / 2).  Split in the part that depends on |x| only (the table build evaluates it
+// once for +x and -x) and the signed tail.
+struct GeluCore {
+    float erf_abs, e;                                  // erf(|x| / sqrt 2), exp(-x^2 / 2)
+};
+__device__ __forceinline__ GeluCore gelu_core(float ax) {
+    const float az = ax * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.f));
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);
     poly = fmaf(poly, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);      // exp(-x^2/2)
-    const float erfv = copysignf(fmaf(-poly * t, e, 1.f), z);
-    const float cdf = fmaf(0.5f, erfv, 0.5f);
-    y = x * cdf;
-    dy = fmaf(x * 0.3989422804014327f, e, cdf);
+    GeluCore c;
+    c.e = __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);
+    c.erf_abs = fmaf(-poly * t, c.e, 1.f);
+    return c;
 }
+__device__ __forceinline__ void gelu_tail(float x, const GeluCore& c, float& y, float& dy) {
+    const float cdf = fmaf(0.5f, copysignf(c.erf_abs, x), 0.5f);
+    y = x * cdf;
+    dy = fmaf(x * 0.3989422804014327f, c.e, cdf);
+}
+__device__ __forceinline__ void gelu_val_grad(float x, float& y, float& dy) { gelu_tail(x, gelu_core(fabsf(x)), y, dy); }
 
 // Derivative factor as one byte: act'(pre) * mask = (code - ZERO) * STEP.  GELU' lies in [-0.1288, 1.1288]: STEP ~ 0.005
 // covers [-0.135, 1.139] with |error| <= 0.0025 (bf16 rounds a factor near 1 by up to 0.0039); its low 8 mantissa bits
@@ -92,6 +101,29 @@ struct FacCode {
         return w;
     }
 };
+
+// GELU by table (EPI_ACT, bf16 pre-activations).  The epilogue's operand is the pre-activation ROUNDED TO bf16, so
+// gelu(x) * keep_scale (bf16) and the code of gelu'(x) are functions of 16 bits: the workgroup tabulates them in its
+// prologue (gelu_val_grad's own arithmetic, 7 pairs +-x per thread, under the wait for the first K tile) for
+// 2^-20 <= |x| < 128 and the epilogue replaces erf + exp + encode (~20 VALU per element, the largest part of this epilogue:
+// 58 of the 127 us it adds at M=32768 N=4096 K=1024) by one 4-byte LDS gather.  Entry = bf16(y) | code << 16; one more
+// entry per sign holds the dropped element (+-0, code ZERO), so dropout is a select on the index.  Elements outside the
+// table (|x| < 2^-20 or >= 128, inf, nan: about one per million) raise a flag and the wave redoes that 16 x 32 block on
+// the arithmetic path: the results are bit-identical to that path everywhere.
+constexpr int GT_LO = 107 << 7, GT_HI = (133 << 7) | 127, GT_NE = GT_HI - GT_LO + 1;   // exponent|mantissa of |x|
+constexpr int GT_SIGN = 16384;                       // byte distance of the negative half (> 4 * (GT_NE + 1))
+constexpr int GT_OFF = 2 * LDS_B;                    // the table follows the staging buffers
+constexpr int GT_BYTES = GT_SIGN + 4 * (GT_NE + 1);
+static_assert(4 * (GT_NE + 1) <= GT_SIGN && (GT_OFF & (2 * GT_SIGN - 1)) == 0, "the sign bit of the offset must be free");
+static_assert(GT_OFF + GT_BYTES <= 160 * 1024, "LDS of a CU");
+// byte offset (from smem) of the entry of the bf16 value with exponent|mantissa em and sign mask sgn (0 / -1); odd
+// becomes non-zero for the values the table does not hold
+__device__ __forceinline__ unsigned gelu_tab_off(unsigned em, int sgn, bool keep, unsigned& odd) {
+    unsigned t = min(max(em, (unsigned)GT_LO), (unsigned)GT_HI);        // v_med3_u32
+    odd |= t ^ em;                                                       // outside the table (one v_bitop3_b32)
+    t = keep ? t : (unsigned)(GT_HI + 1);
+    return ((unsigned)sgn & (unsigned)GT_SIGN) | ((t << 2) + (unsigned)(GT_OFF - 4 * GT_LO));
+}
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
     union { bf16x2 v; unsigned u; } x;
@@ -120,7 +152,8 @@ __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 
 template <int EPI, int ACT, bool DROP, bool HALF>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
     constexpr int BMT = HALF ? 128 : BM, NQA = HALF ? 1 : 2;
-    __shared__ __attribute__((aligned(16))) char smem[2 * LDS_B];
+    constexpr bool TAB = EPI == EPI_ACT && ACT == MGX_ACT_GELU;
+    __shared__ __attribute__((aligned(16))) char smem[2 * LDS_B + (TAB ? GT_BYTES : 0)];
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -219,6 +252,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
     stage_a(1, 0, 0);
     stage_a(0, 1, 1);
     stage_b(0, 1, 1);
+    if constexpr (TAB) {
+        // the GELU table, while the first K tile is on its way; every wave passes an lgkmcnt(0) and a barrier in the
+        // first K step, long before the epilogue reads it
+        unsigned* const tab = reinterpret_cast<unsigned*>(smem + GT_OFF);
+        const float ks = mgx_keep_scale(mgx_drop_thr16(g.p_drop));
+#pragma unroll 1
+        for (int em = tid; em < GT_NE; em += NTHREADS) {
+            const float x = __uint_as_float((unsigned)(GT_LO + em) << 16);
+            const GeluCore c = gelu_core(x);
+#pragma unroll
+            for (int sgn = 0; sgn < 2; ++sgn) {
+                float y, f;
+                gelu_tail(sgn ? -x : x, c, y, f);
+                if (DROP) y *= ks;
+                const float fa[4] = {f, 0.f, 0.f, 0.f};
+                tab[sgn * (GT_SIGN / 4) + em] = (pack2(y, 0.f) & 0xFFFFu) | ((FacCode<ACT>::enc4(fa) & 0xFFu) << 16);
+            }
+        }
+        if (tid < 2) tab[tid * (GT_SIGN / 4) + GT_NE] = ((unsigned)tid << 15) | ((unsigned)FacCode<ACT>::ZERO << 16);
+    }
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // A0(0), B0(0), B1(0) landed
     NT_BAR();
     if (wr == 1) NT_BAR();                                     // waves 4-7 run one barrier behind waves 0-3
@@ -308,7 +361,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) csum[qb][j][r] = 0.f;
         }
-    auto block = [&](int qa, int qb, int i) {
+    unsigned odd = 0;                                    // (TAB) non-zero: an element the table does not hold
+    auto block = [&](int qa, int qb, int i, auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
         const int nb = n0 + NT_COL0(wc, qb);
         const int m = m0 + 128 * qa + 64 * wr + 16 * i + l15;
         const bool row_ok = m < g.M;
@@ -363,6 +418,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = nb + 16 * j + 4 * g4;
+                if constexpr (FAST) {
+                    bool k[4] = {true, true, true, true};
+                    if (DROP) {
+                        mgx_keep_pair(g.seed, (unsigned long long)((long)mc * g.N + n), thr16, k[0], k[1]);
+                        mgx_keep_pair(g.seed, (unsigned long long)((long)mc * g.N + n + 2), thr16, k[2], k[3]);
+                    }
+                    unsigned e[4];
+#pragma unroll
+                    for (int hw = 0; hw < 2; ++hw) {
+                        const unsigned wd = o[j][hw];
+                        const unsigned a0 = gelu_tab_off(wd & 0x7FFFu, (int)(wd << 16) >> 31, k[2 * hw], odd);
+                        const unsigned a1 = gelu_tab_off((wd >> 16) & 0x7FFFu, (int)wd >> 31, k[2 * hw + 1], odd);
+                        e[2 * hw] = *reinterpret_cast<const unsigned*>(smem + a0);
+                        e[2 * hw + 1] = *reinterpret_cast<const unsigned*>(smem + a1);
+                    }
+                    o2[j][0] = __builtin_amdgcn_perm(e[1], e[0], 0x05040100u);
+                    o2[j][1] = __builtin_amdgcn_perm(e[3], e[2], 0x05040100u);
+                    o[j][0] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(e[3], e[2], 0x0C0C0602u),
+                                                    __builtin_amdgcn_perm(e[1], e[0], 0x0C0C0602u), 0x05040100u);
+                    continue;
+                }
                 float y[4], f[4];
                 const float x[4] = {bf_lo(o[j][0]), bf_hi(o[j][0]), bf_lo(o[j][1]), bf_hi(o[j][1])};
 #pragma unroll
@@ -419,7 +495,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(NtArgs g) {
 #pragma unroll
         for (int qa = 0; qa < NQA; ++qa)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) block(qa, qb, i);
+            for (int i = 0; i < 4; ++i) {
+                odd = 0;
+                block(qa, qb, i, std::bool_constant<TAB>{});
+                if constexpr (TAB) {
+                    // wave-uniform and rare: the block again on the arithmetic path (same stores, same values for the
+                    // elements the table holds)
+                    if (__builtin_amdgcn_ballot_w64(odd != 0) != 0) block(qa, qb, i, std::false_type{});
+                }
+            }
     if (EPI == EPI_DFAC && g.colpart) {
         // wave's partial column sums over its 128 rows of this tile: reduce the 16 lanes of a row group
         // (xor 1, 2, 4, 8), then lane l15 == 0 of each g4 adds 4 values per j.  Two wave rows (wr) share a

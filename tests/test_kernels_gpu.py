@@ -594,6 +594,54 @@ def test_gemm_nt_dropout_matches_bias_act_mask():
     assert torch.equal(dpre != 0, kept)
 
 
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_gemm_nt_gelu_epilogue_at_the_edges_of_its_table(p):
+    """The GELU epilogue reads gelu / gelu' of the bf16 pre-activation from an LDS table (2^-20 <= |x| < 128) and redoes
+    a block arithmetically when it meets anything else.  Pre-activations set through the bias (x = 0): zeros, values
+    below, inside and above the table, its first and last rows, inf and nan - every one must come out as F.gelu of the
+    rounded pre-activation (to a bf16 ulp), infinities and NaNs included, with the dropout of (seed, index) on top."""
+    ops = _ops()
+    M, N, K, seed = 300, 264, 64, 31337
+    g = torch.Generator().manual_seed(9)
+    bias = torch.randn(N, generator=g)
+    special = [0.0, -0.0, 1e-9, -3e-8, 2e-6, 2.0 ** -20, -(2.0 ** -20), 0.9e-6, 300.0, -300.0, 100.0, -100.0, 127.5, 128.0,
+               -128.0, float("inf"), float("-inf"), float("nan"), 1.0, -1.0, 0.5, -0.75, 3.0, -3.0, 5.5, -5.5, 15.9, -16.0, 1e30]
+    bias[:len(special)] = torch.tensor(special)
+    bias[100:100 + len(special)] = torch.tensor(special)            # again in another 16-column group of the tile
+    x = torch.zeros(M, K).bfloat16().cuda()
+    w = torch.randn(N, K, generator=g).bfloat16().cuda()
+    fac, h = ops.gemm_nt(x, w, bias.cuda(), None, "gelu", p, seed)
+    pre = bias.bfloat16().float().expand(M, N).clone().requires_grad_(True)
+    y = torch.nn.functional.gelu(pre)
+    torch.nan_to_num(y, nan=0.0, posinf=0.0, neginf=0.0).sum().backward()
+    y, x0 = y.detach(), pre.detach()
+    hf, codes = h.float().cpu(), fac.cpu()
+    # a dropped element: code ZERO and +-0 (a kept one that looks the same - x <= -16 - is zero either way)
+    keep = ~((codes == ops.FAC_ZERO) & (hf == 0))
+    if p > 0:
+        _, h_un = ops.bias_act_fwd(x0.bfloat16().cuda(), None, "gelu", p, seed)        # the mask of (seed, index)
+        nz = torch.isfinite(y) & (y != 0)
+        assert torch.equal((hf != 0)[nz], (h_un.float().cpu() != 0)[nz])
+        assert abs(float(keep[nz].float().mean()) - (1 - p)) < 0.03
+        hf = hf * (1 - p)
+    else:
+        assert bool(keep[torch.isfinite(y) & (y != 0)].all())
+    # inf and nan stay visible (gelu(+inf) is +inf here and nan in torch's CPU kernel: non-finite either way)
+    assert torch.equal(~torch.isfinite(hf) & keep, ~torch.isfinite(y) & keep)
+    assert bool(torch.isnan(hf[torch.isnan(x0) & keep]).all())
+    ok = torch.isfinite(y) & keep
+    # bf16 rounding of the result + the 1.5e-7 absolute error of the erf formula
+    tol = (2.0 ** -7) * y.abs() + 4e-7 * x0.abs().clamp(max=16.0)
+    assert bool(((hf - y).abs()[ok] <= tol[ok]).all())
+    big = (x0 >= 128) & ok
+    assert torch.equal((hf[big] / (1 - p) if p > 0 else hf[big]).bfloat16(), (x0[big] * (1 / (1 - p) if p > 0 else 1.0)).bfloat16())
+    assert float(hf[(x0 <= -16) & torch.isfinite(x0)].abs().max()) == 0.0
+    got = ops.decode_fac(fac, "gelu").cpu()
+    fin_g = ok & torch.isfinite(pre.grad) & torch.isfinite(x0)
+    assert float((got - pre.grad).abs()[fin_g].max()) <= 0.5 * ops.FAC_STEP["gelu"] + 1e-3
+    assert float(got[~keep].abs().max() if bool((~keep).any()) else 0.0) == 0.0
+
+
 @pytest.mark.parametrize("K,M,N", [(64, 256, 256), (1000, 264, 520), (8192, 1024, 3072), (333, 64, 128)])
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
 def test_gemm_tn(K, M, N, out_dtype):
